@@ -1,0 +1,331 @@
+"""Generate the golden fixtures tests/golden/*.npz by RUNNING THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference):   python tests/golden/gen_golden.py
+Fixtures are data only (inputs + the reference's outputs, fp64); seeds are recorded.  The
+reference code is imported in place through ref_import.py (stubs + 3 shims, see there).
+
+What is pinned:
+  ka_*      the reference's own known-answer test arrays (tests/test_warp.py:96-195,
+            tests/test_event_image_converter.py:17-110), re-verified against the reference here
+  warp_*    Warp.warp_event for 2-DoF / dense / voxel, directions first/middle/last/float
+  vote_*    bilinear_vote_tensor / count_event_tensor incl. weights, padding, out-of-image votes
+  blur_*    create_image_from_events_tensor(sigma>0) (shim (1))
+  cost_*    every cost class: value + autograd gradient w.r.t. the IWE(s) / flow
+  burgers_* / upwind_* / voxel_*   single steps, voxel construction, and their VJPs
+  obj_*     one full objective evaluation through the reference's get_arg_for_cost +
+            cost.calculate + torch.autograd.grad, for model x cost x sigma
+  hvp_*     one vhp through torch.autograd.functional.vhp
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+src = ref_import.import_reference()
+from src import costs, event_image_converter, utils, warp  # noqa: E402
+from src.solver.patch_contrast_base import PatchContrastMaximization  # noqa: E402
+
+SEED = 46  # src/utils/misc.py:18
+
+
+def save(name, **arrays):
+    arrays["shims"] = np.array(ref_import.SHIMS)
+    arrays["seed"] = np.array(SEED)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items() if k not in ("shims", "seed")})
+
+
+def make_events(n, H, W, rng, fractional=False, tmin=0.0, tmax=0.05):
+    """Semantics of src/utils/event_utils.py:18-47 (integer pixel coords, sorted uniform t)."""
+    x = rng.integers(0, H, n).astype(np.float64)
+    y = rng.integers(0, W, n).astype(np.float64)
+    if fractional:
+        x = np.clip(x + rng.uniform(0, 0.999, n), 0, H - 1e-3)
+        y = np.clip(y + rng.uniform(0, 0.999, n), 0, W - 1e-3)
+    t = np.sort(rng.uniform(tmin, tmax, n))
+    p = rng.integers(0, 2, n).astype(np.float64)
+    return np.stack([x, y, t, p], axis=1)
+
+
+def smooth_flow(H, W, rng, mag):
+    """Bilinear upsample of a coarse random grid -- the kind of field the solver produces."""
+    g = torch.from_numpy(rng.uniform(-mag, mag, (1, 2, 5, 6)))
+    f = torch.nn.functional.interpolate(g, size=(H, W), mode="bilinear", align_corners=True)[0]
+    return f.numpy().copy()
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_known_answers():
+    # tests/test_warp.py:96-139
+    events = np.array([[1, 2, 0], [2, 3, 0.2], [0, 1, 0.6], [1, 0, 1.0]])
+    flow = np.array(
+        [[[1.0, -0.5, 2, 8], [-2, 0, 2.0, 0], [2, 1, -2, 0]], [[-10, 1.0, 3, 2], [0, 2, -0.9, 0], [0, 10, -3, 0]]]
+    )
+    expected = np.array([[1.0, 2.0, 0], [2.0, 3.0, 0.2], [0.3, 0.4, 0.6], [3, 0, 1.0]])
+    w = warp.Warp((3, 4), normalize_t=True)
+    got, _ = w.warp_event(torch.from_numpy(events), torch.from_numpy(flow), "dense-flow")
+    assert torch.allclose(got, torch.from_numpy(expected))
+    save("ka_warp_dense", events=events, flow=flow, expected=expected, image_size=np.array([3, 4]))
+
+    # tests/test_event_image_converter.py:17-42 and 45-69
+    imager = event_image_converter.EventImageConverter((3, 4))
+    ev_i = np.array([[1.0, 2], [0, 1], [1, 0]])
+    w_i = np.array([1, 2, 0.8])
+    exp_i = np.array([[0, 2, 0, 0], [0.8, 0, 1, 0], [0, 0, 0, 0]])
+    got = imager.bilinear_vote_tensor(torch.from_numpy(ev_i), weight=torch.from_numpy(w_i))
+    assert torch.allclose(got, torch.from_numpy(exp_i))
+    ev_f = np.array([[1.2, 2], [0, 1.9], [0.5, 0.6]])
+    w_f = np.array([-1.0, 1.0, 1.5])
+    exp_f = np.array([[0.3, 0.55, 0.9, 0], [0.3, 0.45, -0.8, 0], [0, 0, -0.2, 0]])
+    got = imager.bilinear_vote_tensor(torch.from_numpy(ev_f), weight=torch.from_numpy(w_f))
+    assert torch.allclose(got, torch.from_numpy(exp_f))
+    save("ka_vote", ev_int=ev_i, w_int=w_i, exp_int=exp_i, ev_float=ev_f, w_float=w_f, exp_float=exp_f,
+         image_size=np.array([3, 4]))
+
+
+def gen_warps(rng):
+    H, W = 26, 34
+    ev = make_events(800, H, W, rng)
+    ev_frac = make_events(300, H, W, rng, fractional=True)
+    theta = np.array([12.3, -7.7])
+    flow = rng.uniform(-5, 5, (2, H, W))
+    T = 10
+    voxel = utils.construct_dense_flow_voxel_numpy(smooth_flow(H, W, rng, 6.0), T, "burgers", "middle")
+    out = {"events": ev, "events_frac": ev_frac, "theta": theta, "flow": flow, "voxel": voxel,
+           "image_size": np.array([H, W])}
+    w = warp.Warp((H, W), normalize_t=True)
+    w_raw = warp.Warp((H, W), normalize_t=False)
+    for d in ["first", "middle", "last", 0.3]:
+        tag = d if isinstance(d, str) else "f0p3"
+        for name, e in (("int", ev), ("frac", ev_frac)):
+            te = torch.from_numpy(e)
+            out[f"2dof_{name}_{tag}"] = w.warp_event(te, torch.from_numpy(theta), "2d-translation", d)[0].numpy()
+            out[f"dense_{name}_{tag}"] = w.warp_event(te, torch.from_numpy(flow), "dense-flow", d)[0].numpy()
+            out[f"voxel_{name}_{tag}"] = w.warp_event(te, torch.from_numpy(voxel), "dense-flow-voxel", d)[0].numpy()
+        out[f"2dof_int_raw_{tag}"] = w_raw.warp_event(torch.from_numpy(ev), torch.from_numpy(theta), "2d-translation", d)[0].numpy()
+    # numpy branch agrees (sanity, not stored)
+    np.testing.assert_allclose(w.warp_event(ev, flow, "dense-flow", "middle")[0], out["dense_int_middle"], rtol=0, atol=1e-12)
+    save("warp", **out)
+
+
+def gen_votes(rng):
+    H, W = 20, 30
+    n = 1500
+    # coordinates spread beyond the image on every side (-3 .. H+2) incl. exact integers and negatives
+    xy = np.stack([rng.uniform(-3, H + 2, n), rng.uniform(-3, W + 2, n)], axis=1)
+    xy[:100] = np.round(xy[:100])
+    ev = np.concatenate([xy, np.zeros((n, 2))], axis=1)
+    wt = rng.uniform(-1, 2, n)
+    out = {"events": ev, "weight": wt, "image_size": np.array([H, W])}
+    for pad in (0, 3):
+        imager = event_image_converter.EventImageConverter((H, W), outer_padding=pad)
+        te = torch.from_numpy(ev)
+        out[f"vote_pad{pad}"] = imager.bilinear_vote_tensor(te).numpy()
+        out[f"vote_w_pad{pad}"] = imager.bilinear_vote_tensor(te, weight=torch.from_numpy(wt)).numpy()
+        # count_event_tensor raises on current torch (int64 `vals` scatter-added into a float image,
+        # event_image_converter.py:251-254) -> the numpy branch is the only runnable count path
+        out[f"count_pad{pad}"] = imager.count_event_numpy(ev)
+        out[f"vote_numpy_pad{pad}"] = imager.bilinear_vote_numpy(ev)  # eps = 1e-8 branch
+        out[f"mask_pad{pad}"] = imager.create_eventmask(te).numpy()
+        for sigma in (1, 0.7):
+            out[f"iwe_s{sigma}_pad{pad}"] = imager.create_iwe(te, "bilinear_vote", sigma).numpy()
+        # autograd of the vote w.r.t. coordinates and weights, random cotangent
+        G = rng.normal(size=out[f"vote_pad{pad}"].shape)
+        te_g = torch.from_numpy(ev).requires_grad_()
+        tw_g = torch.from_numpy(wt).requires_grad_()
+        img = imager.bilinear_vote_tensor(te_g, weight=tw_g)
+        ge, gw = torch.autograd.grad((img * torch.from_numpy(G)).sum(), [te_g, tw_g])
+        out[f"G_pad{pad}"] = G
+        out[f"gxy_pad{pad}"] = ge.numpy()[:, :2]
+        out[f"gw_pad{pad}"] = gw.numpy()
+    save("vote", **out)
+
+
+def gen_costs(rng):
+    H, W = 26, 34
+    ev = make_events(3000, H, W, rng, fractional=True)
+    imager = event_image_converter.EventImageConverter((H, W))
+    iwe = imager.create_iwe(torch.from_numpy(ev), "bilinear_vote", 0).numpy()
+    iwe2 = imager.create_iwe(torch.from_numpy(make_events(3000, H, W, rng, fractional=True)), "bilinear_vote", 1).numpy()
+    iwe3 = imager.create_iwe(torch.from_numpy(make_events(2500, H, W, rng, fractional=True)), "bilinear_vote", 1).numpy()
+    orig = imager.create_iwe(torch.from_numpy(make_events(3000, H, W, rng)), "bilinear_vote", 1).numpy()
+    out = {"iwe": iwe, "iwe2": iwe2, "iwe3": iwe3, "orig": orig}
+    kw = dict(store_history=False, precision="64", cuda_available=False)
+    for name in ["image_variance", "gradient_magnitude", "normalized_image_variance", "normalized_gradient_magnitude",
+                 "multi_focal_normalized_image_variance", "multi_focal_normalized_gradient_magnitude"]:
+        for direction in ["minimize", "natural", "maximize"]:
+            for omit in (True, False):
+                c = costs.functions[name](direction=direction, **kw)
+                t = {k: torch.from_numpy(v).requires_grad_() for k, v in
+                     (("iwe", iwe), ("forward_iwe", iwe2), ("middle_iwe", iwe3), ("orig_iwe", orig))}
+                arg = {"iwe": t["iwe"], "backward_iwe": t["iwe"], "forward_iwe": t["forward_iwe"],
+                       "middle_iwe": t["middle_iwe"], "orig_iwe": t["orig_iwe"], "omit_boundary": omit}
+                loss = c.calculate(arg)
+                used = [k for k in ("iwe", "forward_iwe", "middle_iwe") if k in c.required_keys or
+                        (k == "iwe" and "backward_iwe" in c.required_keys)]
+                gs = torch.autograd.grad(loss, [t[k] for k in used], allow_unused=True)
+                tag = f"{name}__{direction}__omit{int(omit)}"
+                out[tag + "__loss"] = np.array(loss.item())
+                for k, g in zip(used, gs):
+                    out[tag + "__g_" + k] = g.numpy() if g is not None else np.zeros_like(iwe)
+    # numpy-branch variance (biased) for the ddof=0 path
+    out["image_variance_numpy__minimize__omit1"] = np.array(
+        costs.functions["image_variance"](direction="minimize").calculate({"iwe": iwe, "omit_boundary": True}))
+    # total variation on a patch-flow array
+    for shape in ((2, 4, 4), (2, 8, 8), (2, 2, 2), (2, 1, 1)):
+        fl = rng.uniform(-3, 3, shape)
+        for omit in (True, False):
+            c = costs.functions["total_variation"](direction="minimize", **kw)
+            tf = torch.from_numpy(fl).requires_grad_()
+            loss = c.calculate({"flow": tf, "omit_boundary": omit})
+            (g,) = torch.autograd.grad(loss, tf)
+            tag = f"tv_{shape[1]}x{shape[2]}_omit{int(omit)}"
+            out[tag + "__flow"] = fl
+            out[tag + "__loss"] = np.array(loss.item())
+            out[tag + "__g"] = g.numpy()
+    save("costs", **out)
+
+
+def gen_flow_voxel(rng):
+    H, W = 16, 20
+    out = {}
+    flows = {"rand": rng.uniform(-1, 1, (2, H, W)), "smooth": smooth_flow(H, W, rng, 8.0)}
+    flows["withzeros"] = flows["smooth"].copy()
+    flows["withzeros"][:, 5:9, 7:12] = 0.0  # exercises sign(0) / max-min ties
+    for fname, fl in flows.items():
+        out[f"flow_{fname}"] = fl
+        for dt in (0.1, -0.1, 0.01, -0.037, 0.0):
+            tag = f"{fname}_dt{dt}"
+            for scheme, fn in (("burgers", utils.inviscid_burger_flow_to_voxel_torch), ("upwind", utils.upwind_flow_to_voxel_torch)):
+                tf = torch.from_numpy(fl).requires_grad_()
+                o = fn(tf, dt, 1, 1)
+                out[f"{scheme}_step_{tag}"] = o.detach().numpy()
+                if dt != 0.0:
+                    cot = rng.normal(size=(2, H, W))
+                    (g,) = torch.autograd.grad((o * torch.from_numpy(cot)).sum(), tf)
+                    out[f"{scheme}_cot_{tag}"] = cot
+                    out[f"{scheme}_vjp_{tag}"] = g.numpy()
+        for scheme in ("burgers", "upwind"):
+            if fname == "rand":
+                continue
+            for T, loc in ((10, "middle"), (5, "middle"), (4, "first")):
+                tf = torch.from_numpy(fl).requires_grad_()
+                V = utils.construct_dense_flow_voxel_torch(tf, T, scheme, loc)
+                Vn = utils.construct_dense_flow_voxel_numpy(fl, T, scheme, loc)
+                np.testing.assert_allclose(V.detach().numpy(), Vn, rtol=0, atol=1e-10)
+                cot = rng.normal(size=tuple(V.shape))
+                (g,) = torch.autograd.grad((V * torch.from_numpy(cot)).sum(), tf)
+                tag = f"{scheme}_{fname}_T{T}_{loc}"
+                out[f"voxel_{tag}"] = V.detach().numpy()
+                out[f"voxel_cot_{tag}"] = cot
+                out[f"voxel_vjp_{tag}"] = g.numpy()
+    save("flow_voxel", **out)
+
+
+def _fake_solver(H, W, cost_name, sigma, pad=0, cost_with_weight=None, method="bilinear_vote"):
+    """The attributes get_arg_for_cost / calculate_cost read (patch_contrast_base.py:273-352),
+    built exactly as SolverBase.__init__ builds them (solver/base.py:139-147, 177-209)."""
+    kw = dict(direction="minimize", store_history=False, image_size=(H + pad, W + pad), percentile=1.0,
+              precision="64", cuda_available=False)
+    if cost_name == "hybrid":
+        cf = costs.HybridCost(cost_with_weight=cost_with_weight, **kw)
+    else:
+        cf = costs.functions[cost_name](**kw)
+    return types.SimpleNamespace(
+        cost_func=cf,
+        imager=event_image_converter.EventImageConverter((H, W), outer_padding=pad),
+        warper=warp.Warp((H, W), calculate_feature=True, normalize_t=True),
+        iwe_config={"method": method, "blur_sigma": sigma},
+    )
+
+
+def _ref_objective(fs, ev, motion, model, coarse):
+    te = torch.from_numpy(ev)
+    tm = torch.from_numpy(motion).requires_grad_()
+    tc = torch.from_numpy(coarse).requires_grad_() if coarse is not None else None
+    arg = PatchContrastMaximization.get_arg_for_cost(fs, te, tm, model, tc)
+    loss = fs.cost_func.calculate(arg)
+    ins = [tm] + ([tc] if tc is not None and "flow" in fs.cost_func.required_keys else [])
+    gs = torch.autograd.grad(loss, ins, allow_unused=True)
+    iwes = {k: v.detach().numpy() for k, v in arg.items() if k.endswith("iwe")}
+    return loss.item(), gs, iwes
+
+
+def gen_objectives(rng):
+    out = {}
+    H, W = 32, 40
+    ev = make_events(3000, H, W, rng)
+    theta = np.array([23.4, -17.7])  # large enough to push events out of the image
+    flow_rand = rng.uniform(-5, 5, (2, H, W))
+    flow_smooth = smooth_flow(H, W, rng, 20.0)
+    T = 10
+    voxel = utils.construct_dense_flow_voxel_numpy(smooth_flow(H, W, rng, 12.0), T, "burgers", "middle")
+    coarse = rng.uniform(-3, 3, (2, 4, 4))
+    out.update(events=ev, theta=theta, flow_rand=flow_rand, flow_smooth=flow_smooth, voxel=voxel, coarse=coarse,
+               image_size=np.array([H, W]))
+    motions = {"2dof": ("2d-translation", theta), "dense_rand": ("dense-flow", flow_rand),
+               "dense_smooth": ("dense-flow", flow_smooth), "voxel": ("dense-flow-voxel", voxel)}
+    yaml_hybrid = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01}
+    cases = [(c, s, None) for c in ("image_variance", "gradient_magnitude") for s in (0, 1)]
+    cases += [(c, 1, None) for c in ("normalized_image_variance", "normalized_gradient_magnitude",
+                                     "multi_focal_normalized_image_variance",
+                                     "multi_focal_normalized_gradient_magnitude")]
+    cases += [("hybrid", 1, yaml_hybrid)]
+    for mname, (model, motion) in motions.items():
+        for cost_name, sigma, cww in cases:
+            fs = _fake_solver(H, W, cost_name, sigma, cost_with_weight=cww)
+            loss, gs, iwes = _ref_objective(fs, ev, motion, model, coarse)
+            tag = f"{mname}__{cost_name}__s{sigma}"
+            out[tag + "__loss"] = np.array(loss)
+            out[tag + "__grad"] = gs[0].numpy()
+            if len(gs) > 1 and gs[1] is not None:
+                out[tag + "__grad_coarse"] = gs[1].numpy()
+            if cost_name in ("image_variance", "multi_focal_normalized_gradient_magnitude") and mname in ("2dof", "dense_smooth", "voxel"):
+                for k, v in iwes.items():
+                    out[tag + "__" + k] = v
+    # padding + count method + fractional source coordinates
+    evf = make_events(1500, H, W, rng, fractional=True)
+    out["events_frac"] = evf
+    for pad in (0, 4):
+        fs = _fake_solver(H, W, "image_variance", 1, pad=pad)
+        loss, gs, iwes = _ref_objective(fs, evf, theta, "2d-translation", None)
+        out[f"frac_pad{pad}__loss"] = np.array(loss)
+        out[f"frac_pad{pad}__grad"] = gs[0].numpy()
+        out[f"frac_pad{pad}__iwe"] = iwes["iwe"]
+    save("objective", **out)
+
+
+def gen_hvp(rng):
+    H, W = 32, 40
+    ev = make_events(2000, H, W, rng)
+    fs = _fake_solver(H, W, "image_variance", 1)
+    te = torch.from_numpy(ev)
+
+    def f(m):
+        arg = PatchContrastMaximization.get_arg_for_cost(fs, te, m, "2d-translation", None)
+        return fs.cost_func.calculate(arg)
+
+    theta = torch.tensor([13.4, -7.7], dtype=torch.float64)
+    v = torch.tensor([0.3, 1.1], dtype=torch.float64)
+    loss, hv = torch.autograd.functional.vhp(f, theta, v)
+    save("hvp", events=ev, theta=theta.numpy(), v=v.numpy(), loss=np.array(loss.item()), vhp=hv.numpy(),
+         image_size=np.array([H, W]))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(SEED)
+    np.random.seed(SEED)
+    rng = np.random.default_rng(SEED)
+    gen_known_answers()
+    gen_warps(rng)
+    gen_votes(rng)
+    gen_costs(rng)
+    gen_flow_voxel(rng)
+    gen_objectives(rng)
+    gen_hvp(rng)

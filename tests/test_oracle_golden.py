@@ -1,0 +1,171 @@
+"""Pins the CPU oracle (oracle/cmax_oracle.c) to the reference: every check compares an oracle
+function with values produced by the reference itself (tests/golden/gen_golden.py) or with the
+reference's own known-answer test arrays.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+TOL = dict(rtol=1e-11, atol=1e-12)
+
+
+def test_known_answer_dense_warp(golden):
+    g = golden("ka_warp_dense")  # reference tests/test_warp.py:96-139
+    H, W = g["image_size"]
+    warped, _ = orc.warp_event(g["events"], g["flow"], "dense-flow", "first", (H, W))
+    np.testing.assert_allclose(warped[:, :3], g["expected"], **TOL)
+
+
+def test_known_answer_votes(golden):
+    g = golden("ka_vote")  # reference tests/test_event_image_converter.py:17-69
+    size = tuple(g["image_size"])
+    np.testing.assert_array_equal(orc.vote(g["ev_int"], size, weight=g["w_int"]), g["exp_int"])
+    np.testing.assert_allclose(orc.vote(g["ev_float"], size, weight=g["w_float"]), g["exp_float"], **TOL)
+
+
+@pytest.mark.parametrize("tag,direction", [("first", "first"), ("middle", "middle"), ("last", "last"), ("f0p3", 0.3)])
+@pytest.mark.parametrize("kind", ["int", "frac"])
+def test_warps(golden, tag, direction, kind):
+    g = golden("warp")
+    size = tuple(g["image_size"])
+    ev = g["events"] if kind == "int" else g["events_frac"]
+    for model, key, motion in (("2d-translation", "2dof", g["theta"]), ("dense-flow", "dense", g["flow"]),
+                               ("dense-flow-voxel", "voxel", g["voxel"])):
+        warped, _ = orc.warp_event(ev, motion, model, direction, size)
+        np.testing.assert_allclose(warped, g[f"{key}_{kind}_{tag}"], **TOL)
+    if kind == "int":
+        warped, _ = orc.warp_event(ev, g["theta"], "2d-translation", direction, size, normalize_t=False)
+        np.testing.assert_allclose(warped, g[f"2dof_int_raw_{tag}"], **TOL)
+
+
+@pytest.mark.parametrize("pad", [0, 3])
+def test_votes_and_blur(golden, pad):
+    g = golden("vote")
+    size = tuple(g["image_size"])
+    ev = g["events"]
+    np.testing.assert_allclose(orc.vote(ev, size, pad), g[f"vote_pad{pad}"], **TOL)
+    np.testing.assert_allclose(orc.vote(ev, size, pad, weight=g["weight"]), g[f"vote_w_pad{pad}"], **TOL)
+    np.testing.assert_allclose(orc.vote(ev, size, pad, method="count"), g[f"count_pad{pad}"], **TOL)
+    np.testing.assert_allclose(orc.vote(ev, size, pad, eps=1e-8), g[f"vote_numpy_pad{pad}"], **TOL)
+    np.testing.assert_array_equal((orc.vote(ev, size, pad) != 0)[None], g[f"mask_pad{pad}"])
+    for sigma in (1, 0.7):
+        np.testing.assert_allclose(orc.create_iwe(ev, size, pad, sigma=sigma), g[f"iwe_s{sigma}_pad{pad}"], **TOL)
+    gx, gy, gw = orc.vote_bwd(ev, size, g[f"G_pad{pad}"], pad, weight=g["weight"], want_gw=True)
+    np.testing.assert_allclose(np.stack([gx, gy], 1), g[f"gxy_pad{pad}"], **TOL)
+    np.testing.assert_allclose(gw, g[f"gw_pad{pad}"], **TOL)
+
+
+def test_blur_adjoint_is_transpose():
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(7, 9)), rng.normal(size=(7, 9))
+    for sigma in (1.0, 0.6):
+        np.testing.assert_allclose((orc.blur3(a, sigma) * b).sum(), (a * orc.blur3_adj(b, sigma)).sum(), rtol=1e-12)
+    # degenerate sizes
+    for shape in ((1, 5), (5, 1), (2, 2)):
+        a, b = rng.normal(size=shape), rng.normal(size=shape)
+        np.testing.assert_allclose((orc.blur3(a, 1.0) * b).sum(), (a * orc.blur3_adj(b, 1.0)).sum(), rtol=1e-12)
+
+
+COSTS = ["image_variance", "gradient_magnitude", "normalized_image_variance", "normalized_gradient_magnitude",
+         "multi_focal_normalized_image_variance", "multi_focal_normalized_gradient_magnitude"]
+
+
+@pytest.mark.parametrize("name", COSTS)
+@pytest.mark.parametrize("direction", ["minimize", "natural", "maximize"])
+@pytest.mark.parametrize("omit", [True, False])
+def test_costs(golden, name, direction, omit):
+    g = golden("costs")
+    iwes = {"iwe": g["iwe"], "backward_iwe": g["iwe"], "forward_iwe": g["iwe2"], "middle_iwe": g["iwe3"],
+            "orig_iwe": g["orig"]}
+    loss, grads, _ = orc.cost_and_image_grads(name, iwes, omit, direction)
+    tag = f"{name}__{direction}__omit{int(omit)}"
+    np.testing.assert_allclose(loss, g[tag + "__loss"], rtol=1e-11)
+    merged = {}
+    for k, v in grads.items():
+        kk = "iwe" if k == "backward_iwe" else k
+        merged[kk] = merged.get(kk, 0) + v
+    for k in ("iwe", "forward_iwe", "middle_iwe"):
+        if tag + "__g_" + k in g:
+            got = merged.get(k, np.zeros_like(g["iwe"]))
+            ref = g[tag + "__g_" + k]
+            np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-13 * max(1.0, np.abs(ref).max()))
+
+
+def test_variance_numpy_branch(golden):
+    g = golden("costs")
+    v, _ = orc.variance(g["iwe"], True, ddof=0)
+    np.testing.assert_allclose(-v, g["image_variance_numpy__minimize__omit1"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("shape", ["4x4", "8x8", "2x2", "1x1"])
+@pytest.mark.parametrize("omit", [1, 0])
+def test_total_variation(golden, shape, omit):
+    g = golden("costs")
+    tag = f"tv_{shape}_omit{omit}"
+    v, G = orc.total_variation(g[tag + "__flow"], bool(omit))
+    np.testing.assert_allclose(v, g[tag + "__loss"], rtol=1e-12)
+    np.testing.assert_allclose(G, g[tag + "__g"], rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("fname", ["rand", "smooth", "withzeros"])
+@pytest.mark.parametrize("dt", [0.1, -0.1, 0.01, -0.037, 0.0])
+@pytest.mark.parametrize("scheme", ["burgers", "upwind"])
+def test_flow_steps(golden, fname, dt, scheme):
+    g = golden("flow_voxel")
+    fl = g[f"flow_{fname}"]
+    step, adj = (orc.burgers_step, orc.burgers_step_adj) if scheme == "burgers" else (orc.upwind_step, orc.upwind_step_adj)
+    tag = f"{fname}_dt{dt}"
+    np.testing.assert_allclose(step(fl, dt), g[f"{scheme}_step_{tag}"], rtol=1e-11, atol=1e-12)
+    if dt != 0.0:
+        np.testing.assert_allclose(adj(fl, dt, g[f"{scheme}_cot_{tag}"]), g[f"{scheme}_vjp_{tag}"], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("fname", ["smooth", "withzeros"])
+@pytest.mark.parametrize("T,loc", [(10, "middle"), (5, "middle"), (4, "first")])
+@pytest.mark.parametrize("scheme", ["burgers", "upwind"])
+def test_voxel(golden, fname, T, loc, scheme):
+    g = golden("flow_voxel")
+    fl = g[f"flow_{fname}"]
+    tag = f"{scheme}_{fname}_T{T}_{loc}"
+    V = orc.construct_dense_flow_voxel(fl, T, scheme, loc)
+    np.testing.assert_allclose(V, g[f"voxel_{tag}"], rtol=1e-10, atol=1e-11)
+    gF = orc.construct_dense_flow_voxel_adj(V, g[f"voxel_cot_{tag}"], scheme, loc)
+    np.testing.assert_allclose(gF, g[f"voxel_vjp_{tag}"], rtol=1e-9, atol=1e-10)
+
+
+YAML_HYBRID = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01}
+OBJ_CASES = [(c, s) for c in ("image_variance", "gradient_magnitude") for s in (0, 1)] + [
+    (c, 1) for c in ("normalized_image_variance", "normalized_gradient_magnitude",
+                     "multi_focal_normalized_image_variance", "multi_focal_normalized_gradient_magnitude", "hybrid")]
+MOTIONS = {"2dof": ("2d-translation", "theta"), "dense_rand": ("dense-flow", "flow_rand"),
+           "dense_smooth": ("dense-flow", "flow_smooth"), "voxel": ("dense-flow-voxel", "voxel")}
+
+
+@pytest.mark.parametrize("mname", list(MOTIONS))
+@pytest.mark.parametrize("cost,sigma", OBJ_CASES)
+def test_objective(golden, mname, cost, sigma):
+    g = golden("objective")
+    model, mkey = MOTIONS[mname]
+    size = tuple(g["image_size"])
+    res = orc.objective(g["events"], g[mkey], model, size, cost=cost, sigma=sigma,
+                        cost_with_weight=YAML_HYBRID if cost == "hybrid" else None, coarse_flow=g["coarse"])
+    tag = f"{mname}__{cost}__s{sigma}"
+    np.testing.assert_allclose(res["loss"], g[tag + "__loss"], rtol=1e-10)
+    ref = g[tag + "__grad"]
+    np.testing.assert_allclose(res["grad"], ref, rtol=1e-8, atol=1e-11 * max(1.0, np.abs(ref).max()))
+    if tag + "__grad_coarse" in g:
+        np.testing.assert_allclose(res["grad_flow"], g[tag + "__grad_coarse"], rtol=1e-10, atol=1e-14)
+    for k in ("iwe", "forward_iwe", "middle_iwe", "orig_iwe"):
+        if tag + "__" + k in g:
+            np.testing.assert_allclose(res["iwes"][k], g[tag + "__" + k], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("pad", [0, 4])
+def test_objective_fractional_and_padding(golden, pad):
+    g = golden("objective")
+    size = tuple(g["image_size"])
+    res = orc.objective(g["events_frac"], g["theta"], "2d-translation", size, cost="image_variance", sigma=1,
+                        outer_padding=pad)
+    np.testing.assert_allclose(res["loss"], g[f"frac_pad{pad}__loss"], rtol=1e-10)
+    np.testing.assert_allclose(res["grad"], g[f"frac_pad{pad}__grad"], rtol=1e-8)
+    np.testing.assert_allclose(res["iwes"]["iwe"], g[f"frac_pad{pad}__iwe"], rtol=1e-11, atol=1e-12)
