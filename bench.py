@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""Headline benchmark: events/s through ONE objective evaluation = warp + IWE accumulate + cost +
+analytic gradient (BASELINE.json metric), on synthetic events already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE configs[1] = 1M synthetic events, 346x260 (H=260, W=346),
+2-DoF translational flow, image-variance cost + analytic gradient.  For N > 1 every rank owns one
+1M-event time slice of an N x 1M-event batch (weak scaling), with an RCCL all-reduce of the IWE and
+of the gradient per evaluation (event_based_optical_flow_amd/distributed.py).
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration, the duration
+                measured with HIP events on the launch stream in an instrumented pass of the same K
+                steps (cmax_set_profiling); peak = 8.0 TB/s HBM (MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (oracle/cmax_oracle.c, scalar C, 1 core) timed on this host on the
+                same workload -- a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (H, W, n_events per GPU, model, cost, sigma)
+    "cfg2": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0,
+                 desc="cfg2: 1M synthetic events, 346x260, 2-DoF translational flow, image_variance + analytic grad"),
+    "cfg3": dict(H=480, W=640, n=5_000_000, model="dense-flow", cost="gradient_magnitude", sigma=0.0,
+                 desc="cfg3: 5M synthetic events, 640x480, dense per-pixel flow, gradient_magnitude + analytic grad"),
+    "cfg4": dict(H=260, W=346, n=2_000_000, model="dense-flow-voxel", cost="image_variance", sigma=1.0,
+                 desc="cfg4: 2M synthetic events, 346x260, Burgers voxel T=10 (t0 middle) + voxel warp, image_variance"),
+    "cfg5": dict(H=720, W=1280, n=2_500_000, model="dense-flow", cost="image_variance", sigma=0.0,
+                 desc="cfg5: 20M/8 = 2.5M events per GPU, 1280x720, dense flow, image_variance"),
+}
+
+
+def algorithmic_bytes(kernel: str, n: int, H: int, W: int, model: str, T: int) -> float:
+    """per evaluation B = 24 N + 16 HW + B_model, split per kernel as
+    K1 vote : 12 N (x, y, t fp32) + 4 HW (IWE write) + 8 HW T' (flow read, dense / voxel)
+    K3 grad : 12 N               + 4 HW (G read)     + 8 HW T' (flow-gradient write)
+    K2 stats: 4 HW (IWE read);  K2b gimage: 4 HW (G write)                                  """
+    tp = 0 if model == "2d-translation" else (T if model == "dense-flow-voxel" else 1)
+    if kernel in ("vote", "grad"):
+        return 12.0 * n + 4.0 * H * W + 8.0 * H * W * tp
+    return 4.0 * H * W
+
+
+def make_inputs(cfg, rank, world, seed=46):
+    import event_based_optical_flow_amd as E
+
+    H, W, n = cfg["H"], cfg["W"], cfg["n"]
+    period = 0.05
+    # rank r owns the time slice [r, r+1) * period / world of the global batch
+    ev = E.utils.generate_events(n, H, W, tmin=rank * period / world, tmax=(rank + 1) * period / world, seed=seed + rank)
+    T = 0
+    if cfg["model"] == "2d-translation":
+        motion = np.array([12.3, -7.7])
+    elif cfg["model"] == "dense-flow":
+        motion = E.utils.generate_smooth_flow((H, W), 20, seed=seed + 1000)
+    else:
+        T = 10
+        motion = None  # built on the GPU below from the t0 flow
+    return ev, motion, T
+
+
+def cpu_baseline(cfg, ev, motion, budget_s=12.0):
+    """Oracle (fp64 scalar C port of the reference path) on this host, same inputs."""
+    from oracle import oracle as orc
+
+    size = (cfg["H"], cfg["W"])
+    orc.objective(ev[:1000], motion, cfg["model"], size, cost=cfg["cost"], sigma=cfg["sigma"])  # warm the .so
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.objective(ev, motion, cfg["model"], size, cost=cfg["cost"], sigma=cfg["sigma"])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 200:
+            break
+    return {"value": ev.shape[0] * reps / el, "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} full evaluations (value+gradient) of the same {ev.shape[0]}-event workload, "
+                      f"oracle/cmax_oracle.c fp64 scalar C, {el:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--events", default="uniform", choices=["uniform", "structured"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import event_based_optical_flow_amd as E
+    from event_based_optical_flow_amd.distributed import TimeSlicedObjective
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    cfg = WORKLOADS[args.workload]
+    H, W, n = cfg["H"], cfg["W"], cfg["n"]
+    ev, motion, T = make_inputs(cfg, rank, world)
+    if args.events == "structured" and cfg["model"] == "2d-translation":
+        ev = E.utils.generate_structured_events(n, H, W, (12.3, -7.7), n_dots=2500, tmin=rank * 0.05 / world,
+                                                tmax=(rank + 1) * 0.05 / world, seed=46 + rank)
+
+    handle = E.CMaxHandle((H, W))
+    sliced = TimeSlicedObjective(handle)
+    ev_dev = torch.from_numpy(ev).to(dev)  # fp64 [n,4] resident in HBM before anything is timed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sliced.set_local_events(ev_dev, time_bin=T, device=dev)
+    torch.cuda.synchronize()
+    prepare_ms = (time.perf_counter() - t0) * 1e3  # once per batch: pack + counting sort (not in `value`)
+
+    if cfg["model"] == "dense-flow-voxel":
+        f0 = torch.from_numpy(E.utils.generate_smooth_flow((H, W), 20, seed=1046)).to(dev)
+        motion_dev = E.utils.construct_dense_flow_voxel_torch(f0 / 20.0, T, "burgers", "middle").float() * 20.0
+        motion = motion_dev.double().cpu().numpy()
+    else:
+        motion_dev = torch.from_numpy(np.asarray(motion)).to(dev).float().contiguous()
+    desc = E.make_descriptor(cfg["cost"], cfg["model"], sigma=cfg["sigma"], time_bin=T)
+
+    def step():
+        return sliced.evaluate(desc, motion_dev, want_grad=True)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res, grad = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, grad = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss = float(res[0].item())
+
+    # instrumented pass: HIP events around every launch of the four hot kernel classes
+    handle.set_profiling(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof = handle.read_profile()
+    handle.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n * world * args.steps / elapsed
+        per_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof.items()}  # us per launch
+        dominant = max(per_kernel, key=lambda k: per_kernel[k])
+        ab = algorithmic_bytes(dominant, n, H, W, cfg["model"], T)
+        achieved = ab / (per_kernel[dominant] * 1e-6) / 1e9 if per_kernel[dominant] > 0 else 0.0
+        eval_bytes = sum(algorithmic_bytes(k, n, H, W, cfg["model"], T) for k in ("vote", "stats", "gimage", "grad"))
+        out = {
+            "metric": "events/sec through warp+IWE+cost+grad (one objective evaluation)",
+            "value": value,
+            "unit": "events/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (%s events, seed 46)" % args.events,
+            "config": {"workload": cfg["desc"], "events_per_gpu": n, "image": [H, W], "motion_model": cfg["model"],
+                       "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}"},
+            "roofline": {"bound": "hbm", "kernel": {"vote": "k_vote (K1 warp + bilinear vote)", "grad": "k_grad (K3 gather + gradient)",
+                                                    "stats": "k_stats (K2)", "gimage": "k_gimage (K2b)"}[dominant],
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": ab,
+                         "launch_us": per_kernel[dominant],
+                         "method": "HIP events on the launch stream, instrumented pass of the same K steps",
+                         "all_kernels_us": per_kernel,
+                         "evaluation_GBps": eval_bytes / (ms_per_step * 1e-3) / 1e9,
+                         "evaluation_frac": eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "loss": loss,
+            "prepare_ms_once_per_batch": prepare_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, ev, motion)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

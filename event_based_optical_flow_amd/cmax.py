@@ -1,0 +1,264 @@
+"""Fused contrast-maximization objective: the hot path behind the reference's
+`calculate_cost` (src/solver/patch_contrast_base.py:273-352).
+
+`CMaxHandle` owns a `cmax_handle_t`: the batch is packed and sorted once (`set_events`), then every
+objective evaluation runs warp+vote -> contrast -> gather-gradient on the GPU without
+materialising warped events.  `ContrastObjective` exposes it as a differentiable callable
+`loss = objective(motion)` for `scipy_autograd.minimize` / `torch.autograd.grad`.
+"""
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import functional as F
+from ._lib import CmaxObjective, check
+from .array_types import to_device_tensor
+
+_COST_TABLE = {
+    # name: (cost code, normalized, [(direction, multiplier), ...])  -- which IWEs get_arg_for_cost builds
+    "image_variance": (_lib.COST_VARIANCE, 0, (("first", 1.0),)),
+    "gradient_magnitude": (_lib.COST_GRADMAG, 0, (("first", 1.0),)),
+    "normalized_image_variance": (_lib.COST_VARIANCE, 1, (("first", 1.0),)),
+    "normalized_gradient_magnitude": (_lib.COST_GRADMAG, 1, (("first", 1.0),)),
+    # forward = "last", backward = "first", middle x2 (multi_focal_*.py; patch_contrast_base.py:308-347)
+    "multi_focal_normalized_image_variance": (_lib.COST_VARIANCE, 1, (("last", 1.0), ("first", 1.0), ("middle", 2.0))),
+    "multi_focal_normalized_gradient_magnitude": (_lib.COST_GRADMAG, 1, (("last", 1.0), ("first", 1.0), ("middle", 2.0))),
+}
+FUSED_COSTS = tuple(_COST_TABLE)
+
+
+def make_descriptor(cost: str, motion_model: str, direction: str = "minimize", sigma: float = 0.0,
+                    omit_boundary: bool = True, normalize_t: bool = True, time_bin: int = 0,
+                    warp_direction: Union[str, float] = "first") -> CmaxObjective:
+    """Build the cmax_objective_t for one named cost (include/cmax_hip.h)."""
+    if cost not in _COST_TABLE:
+        raise KeyError(f"cost {cost!r} has no fused kernel; fused costs: {FUSED_COSTS}")
+    if motion_model not in F.MODEL_CODES:
+        raise KeyError(motion_model)
+    if direction not in ("minimize", "maximize", "natural"):
+        raise ValueError(f"direction should be minimize, maximize, and natural. Got {direction}.")
+    code, normalized, refs = _COST_TABLE[cost]
+    d = CmaxObjective()
+    d.model = F.MODEL_CODES[motion_model]
+    d.cost = code
+    d.normalized = normalized
+    d.minimize = int(direction == "minimize")
+    # multi_focal_* return -loss for "maximize" (they sum iwe/orig ratios first)
+    d.negate = int(len(refs) > 1 and direction == "maximize")
+    d.omit_boundary = int(bool(omit_boundary))
+    d.normalize_t = int(bool(normalize_t))
+    d.n_ref = len(refs)
+    for k, (ref_dir, mult) in enumerate(refs):
+        if len(refs) == 1:
+            ref_dir = warp_direction
+        mode, frac = F.direction_to_ref(ref_dir)
+        d.ref_mode[k] = mode
+        d.ref_frac[k] = frac
+        d.mult[k] = mult
+    d.sigma = float(sigma)
+    d.T = int(time_bin)
+    return d
+
+
+class CMaxHandle:
+    """One GPU workspace for one event batch (cmax_create / cmax_set_events / cmax_objective)."""
+
+    def __init__(self, image_size: Tuple[int, int], outer_padding: Union[int, Tuple[int, int]] = 0):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        if isinstance(outer_padding, (int, float)):
+            outer_padding = (int(outer_padding), int(outer_padding))
+        self.image_size = (int(image_size[0]), int(image_size[1]))
+        self.outer_padding = (int(outer_padding[0]), int(outer_padding[1]))
+        self.padded_size = (self.image_size[0] + 2 * self.outer_padding[0], self.image_size[1] + 2 * self.outer_padding[1])
+        self._h = ctypes.c_void_p()
+        check(self._lib.cmax_create(self.image_size[0], self.image_size[1], self.outer_padding[0], self.outer_padding[1],
+                                    ctypes.byref(self._h)))
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.time_bin = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.cmax_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def set_events(self, events, tmin: Optional[float] = None, tmax: Optional[float] = None, time_bin: int = 0):
+        """Pack + sort one [n,4] batch (numpy or tensor, fp32/fp64).  (tmin, tmax): global batch
+        extremes when this handle only holds a time slice of the batch (multi-GPU)."""
+        ev = to_device_tensor(events, "events")
+        if ev.dim() != 2 or ev.shape[1] != 4:
+            raise ValueError(f"events must be [n, 4], got {tuple(ev.shape)}")
+        ev = ev.contiguous()
+        have = tmin is not None and tmax is not None
+        check(self._lib.cmax_set_events(self._h, ev.data_ptr(), F._code(ev), ev.shape[0], int(have),
+                                        float(tmin) if have else 0.0, float(tmax) if have else 0.0, int(time_bin),
+                                        F._stream()))
+        self.time_bin = int(time_bin)
+        return self
+
+    def set_time_bins(self, time_bin: int):
+        check(self._lib.cmax_set_time_bins(self._h, int(time_bin), F._stream()))
+        self.time_bin = int(time_bin)
+
+    @property
+    def n_events(self) -> int:
+        n = ctypes.c_int64()
+        check(self._lib.cmax_handle_info(self._h, ctypes.byref(n), None))
+        return n.value
+
+    @property
+    def workspace_bytes(self) -> int:
+        b = ctypes.c_int64()
+        check(self._lib.cmax_handle_info(self._h, None, ctypes.byref(b)))
+        return b.value
+
+    def _motion32(self, motion) -> torch.Tensor:
+        return to_device_tensor(motion, "motion").detach().to(torch.float32).contiguous()
+
+    def iwe(self, motion, motion_model: Optional[str], direction: Union[str, float] = "first",
+            normalize_t: bool = True, sigma: float = 0.0) -> torch.Tensor:
+        """Image of warped events, fp32 [Hp, Wp].  motion_model None -> un-warped image (orig_iwe)."""
+        out = torch.empty(self.padded_size, dtype=torch.float32, device=self.device)
+        if motion_model is None:
+            model, mptr, T = -1, None, 0
+        else:
+            m = self._motion32(motion)
+            model, mptr = F.MODEL_CODES[motion_model], m.data_ptr()
+            T = int(m.shape[0]) if model == _lib.MODEL_VOXEL else 0
+        mode, frac = F.direction_to_ref(direction)
+        check(self._lib.cmax_iwe(self._h, model, mptr, T, mode, frac, int(bool(normalize_t)), float(sigma),
+                                 out.data_ptr(), F._stream()))
+        return out
+
+    def evaluate(self, desc: CmaxObjective, motion, want_grad: bool = True):
+        """One cmax_objective call.  Returns (result double[8] on device, grad or None).
+        result[0] = loss, result[1..n_ref] = raw contrasts, result[5] = contrast of orig_iwe."""
+        m = self._motion32(motion)
+        result = torch.empty(8, dtype=torch.float64, device=self.device)
+        grad = None
+        if want_grad:
+            if desc.model == _lib.MODEL_2DOF:
+                grad = torch.empty(2, dtype=torch.float64, device=self.device)
+            else:
+                grad = torch.empty(tuple(m.shape), dtype=torch.float32, device=self.device)
+        check(self._lib.cmax_objective(self._h, ctypes.byref(desc), m.data_ptr(), result.data_ptr(),
+                                       grad.data_ptr() if grad is not None else None, F._stream()))
+        return result, grad
+
+    # -- phase-split form (time-sliced multi-GPU, see distributed.py) --------------------------------
+    def objective_vote(self, desc: CmaxObjective, motion) -> torch.Tensor:
+        """Raw votes of this handle's events: fp32 [n_images, Hp, Wp] (n_ref images, plus the un-warped
+        image when a normalised cost needs it).  To be all-reduced (sum) across time slices."""
+        m = self._motion32(motion)
+        images = torch.empty((5,) + self.padded_size, dtype=torch.float32, device=self.device)
+        n_images = ctypes.c_int(0)
+        check(self._lib.cmax_objective_vote(self._h, ctypes.byref(desc), m.data_ptr(), images.data_ptr(),
+                                            ctypes.byref(n_images), F._stream()))
+        return images[: n_images.value]
+
+    def objective_finish(self, desc: CmaxObjective, motion, images: torch.Tensor, want_grad: bool = True):
+        """Loss from the (globally reduced) images, gradient contribution of this handle's events."""
+        m = self._motion32(motion)
+        images = images.contiguous()
+        result = torch.empty(8, dtype=torch.float64, device=self.device)
+        grad = None
+        if want_grad:
+            if desc.model == _lib.MODEL_2DOF:
+                grad = torch.empty(2, dtype=torch.float64, device=self.device)
+            else:
+                grad = torch.empty(tuple(m.shape), dtype=torch.float32, device=self.device)
+        check(self._lib.cmax_objective_finish(self._h, ctypes.byref(desc), m.data_ptr(), images.data_ptr(),
+                                              int(images.shape[0]), result.data_ptr(),
+                                              grad.data_ptr() if grad is not None else None, F._stream()))
+        return result, grad
+
+    # -- per-kernel timing (bench.py roofline) ---------------------------------------------------------
+    def set_profiling(self, enable: bool):
+        check(self._lib.cmax_set_profiling(self._h, int(bool(enable))))
+
+    def read_profile(self) -> Dict[str, Tuple[float, int]]:
+        """{kernel class: (total ms, launches)} measured with HIP events on the launch stream."""
+        ms = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_int64 * 4)()
+        check(self._lib.cmax_read_profile(self._h, ms, cnt))
+        names = ("vote", "stats", "gimage", "grad")
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
+
+    def last_iwe(self, k: int = 0) -> torch.Tensor:
+        """Copy of the IWE of reference time k of the last evaluation (fp32 [Hp, Wp])."""
+        out = torch.empty(self.padded_size, dtype=torch.float32, device=self.device)
+        check(self._lib.cmax_copy_iwe(self._h, int(k), out.data_ptr(), F._stream()))
+        return out
+
+
+class _FusedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, motion, handle, desc):
+        need = motion.requires_grad
+        result, grad = handle.evaluate(desc, motion, want_grad=need)
+        ctx.grad = grad
+        ctx.mdtype = motion.dtype
+        ctx.mdevice = motion.device
+        return result[0].to(motion.dtype if motion.dtype.is_floating_point else torch.float64)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.grad
+        if g is None:
+            return None, None, None
+        g = g.to(ctx.mdtype) * gout.to(g.device).to(ctx.mdtype)
+        return g.to(ctx.mdevice), None, None
+
+
+class ContrastObjective:
+    """loss = objective(motion[, coarse_flow]) with the reference's cost names.
+
+    cost: any key of costs.functions, or "hybrid" with cost_with_weight={name: weight | "inv"}
+    (src/costs/hybrid.py).  Event-based costs run as fused kernels on `handle`; total_variation runs
+    on the patch flow handed in as `coarse_flow` (patch_contrast_base.py:349-350)."""
+
+    def __init__(self, handle: CMaxHandle, motion_model: str, cost: str = "image_variance",
+                 cost_with_weight: Optional[Dict[str, Union[float, str]]] = None, direction: str = "minimize",
+                 sigma: float = 0.0, omit_boundary: bool = True, normalize_t: bool = True,
+                 warp_direction: Union[str, float] = "first"):
+        self.handle = handle
+        self.motion_model = motion_model
+        self.direction = direction
+        self.omit_boundary = omit_boundary
+        terms = cost_with_weight if cost == "hybrid" else {cost: 1.0}
+        if cost == "hybrid" and not cost_with_weight:
+            raise ValueError("hybrid cost needs cost_with_weight")
+        self.terms = []
+        for name, weight in terms.items():
+            if name == "total_variation":
+                self.terms.append((name, weight, None))
+            else:
+                desc = make_descriptor(name, motion_model, direction, sigma, omit_boundary, normalize_t,
+                                       handle.time_bin if F.MODEL_CODES[motion_model] == _lib.MODEL_VOXEL else 0,
+                                       warp_direction)
+                self.terms.append((name, weight, desc))
+
+    def __call__(self, motion: torch.Tensor, coarse_flow: Optional[torch.Tensor] = None) -> torch.Tensor:
+        loss = 0.0
+        for name, weight, desc in self.terms:
+            if desc is None:
+                if coarse_flow is None:
+                    raise KeyError("flow")
+                value = F.total_variation(to_device_tensor(coarse_flow, "flow"), self.omit_boundary)
+                if self.direction != "minimize":
+                    value = -value
+            else:
+                value = _FusedFn.apply(motion, self.handle, desc)
+            value = value.to(motion.device) if isinstance(motion, torch.Tensor) else value
+            loss = loss + (1.0 / value if weight == "inv" else weight * value)
+        return loss

@@ -1,0 +1,154 @@
+"""`Warp`: the reference's event-warp class (src/warp.py) over the HIP kernels.
+
+Same constructor, method names, argument meaning and error behaviour as the reference so that
+callers (solvers, tests) switch by changing the import.  The arithmetic runs in
+libcmax_hip.so (cmax_warp_events / cmax_warp_events_bwd); numpy inputs are moved to the GPU and
+back.  Outside the scope: "dense-flow-voxel-optimized", which raises
+AttributeError in the reference itself (src/warp.py:422) and is unreachable from its solvers.
+"""
+import logging
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import functional as F
+from .feature_calculator import skip_feature
+from .array_types import FLOAT_TORCH, NUMPY_TORCH, is_numpy, is_torch, like_input, nt_max, nt_min, to_device_tensor
+
+logger = logging.getLogger(__name__)
+
+
+class MotionModelKeyError(Exception):
+    """Unknown motion model name (reference: src/warp.py:15-21)."""
+
+    def __init__(self, message):
+        e = f"{message = } not supported"
+        logger.error(e)
+        super().__init__(e)
+
+
+_TRANSLATION_MODELS = ("2d-translation", "rigid-optical-flow")
+
+
+class Warp(object):
+    """Event warping with 2-DoF, dense-flow and time-binned (voxel) dense-flow motion models.
+
+    Args:
+        image_size (tuple) ... (H, W).
+        calculate_feature (bool) ... kept for signature compatibility (the reference's feature
+            calculator is a mock).
+        normalize_t (bool) ... normalise dt to a unit period (src/warp.py:254-259).
+    """
+
+    def __init__(self, image_size: tuple, calculate_feature: bool = False, normalize_t: bool = False,
+                 calib_param: Optional[np.ndarray] = None):
+        self.update_property(image_size, calculate_feature, normalize_t, calib_param)
+
+    def update_property(self, image_size=None, calculate_feature=None, normalize_t=None, calib_param=None):
+        if image_size is not None:
+            self.image_size = image_size
+        if calculate_feature is not None:
+            self.calculate_feature = calculate_feature
+        if normalize_t is not None:
+            self.normalize_t = normalize_t
+        if calib_param is not None:
+            self.calib_param = calib_param
+
+    # -- motion-model bookkeeping (src/warp.py:64-153) ------------------------------------------
+    def get_key_names(self, motion_model: str) -> list:
+        if motion_model == "dense-flow" or motion_model in _TRANSLATION_MODELS:
+            return ["trans_x", "trans_y"]
+        raise MotionModelKeyError(motion_model)
+
+    def get_motion_vector_size(self, motion_model: str) -> int:
+        params = {k: 0.0 for k in self.get_key_names(motion_model)}
+        return len(self.motion_model_to_motion(motion_model, params))
+
+    def motion_model_to_motion(self, motion_model: str, params: dict) -> np.ndarray:
+        if motion_model in _TRANSLATION_MODELS:
+            return np.array([params["trans_x"], params["trans_y"]])
+        if motion_model == "dense-flow":
+            return self.get_flow_from_motion(np.array([params["trans_x"], params["trans_y"]]), "2d-translation")
+        raise MotionModelKeyError(motion_model)
+
+    def motion_model_from_motion(self, motion: np.ndarray, motion_model: str) -> dict:
+        if motion_model == "dense-flow" or motion_model in _TRANSLATION_MODELS:
+            return {"trans_x": motion[0], "trans_y": motion[1]}
+        raise MotionModelKeyError(motion_model)
+
+    def get_flow_from_motion(self, motion: NUMPY_TORCH, motion_model: str) -> NUMPY_TORCH:
+        """Dense flow [2,H,W] equivalent to a parametric motion: warp one probe event per pixel at
+        t=1 (plus one at t=0 fixing the reference time) and read the displacement back
+        (src/warp.py:129-153)."""
+        H, W = self.image_size
+        xs, ys = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        probes = np.stack([xs.ravel(), ys.ravel(), np.ones(H * W), np.ones(H * W)], axis=1).astype(np.float64)
+        probes = np.concatenate([np.zeros((1, 4)), probes])
+        events = torch.from_numpy(probes) if is_torch(motion) else probes
+        warped, _ = self.warp_event(events, motion, motion_model)
+        disp = -(warped[1:, :2] - events[1:, :2])
+        if is_torch(motion):
+            return disp.T.reshape(2, H, W)
+        return disp.T.reshape(2, H, W)
+
+    # -- the warp itself --------------------------------------------------------------------------
+    def warp_event(self, events: NUMPY_TORCH, motion: NUMPY_TORCH, motion_model: str,
+                   direction: Union[str, float] = "first", flow_propagate_bin: Optional[int] = None
+                   ) -> Tuple[NUMPY_TORCH, dict]:
+        """events [(b,) n, 4], motion [(b,) ...] -> (warped [(b,) n, 4] = (x', y', dt, p), feature dict).
+
+        Dispatch as src/warp.py:156-199; unknown models raise MotionModelKeyError."""
+        if motion_model in _TRANSLATION_MODELS:
+            assert motion.shape[-1] == 2
+        elif motion_model not in ("dense-flow", "dense-flow-voxel"):
+            raise MotionModelKeyError(motion_model)
+        F.direction_to_ref(direction)  # validates `direction` before touching the GPU (ValueError)
+        ev = to_device_tensor(events, "events")
+        mo = to_device_tensor(motion, "motion").to(ev.dtype)
+        if ev.shape[-1] < 4:  # the reference's tests pass [n,3]; pad a polarity column and strip it after
+            pad = ev.new_zeros(ev.shape[:-1] + (4 - ev.shape[-1],))
+            ev4 = torch.cat([ev, pad], dim=-1)
+        else:
+            ev4 = ev
+        if ev4.dim() == 3:
+            out = torch.stack([F.warp_events(ev4[i], mo[i], motion_model, self.image_size, direction, self.normalize_t)
+                               for i in range(ev4.shape[0])])
+        elif ev4.dim() == 1:
+            out = F.warp_events(ev4[None], mo, motion_model, self.image_size, direction, self.normalize_t)
+        else:
+            out = F.warp_events(ev4, mo, motion_model, self.image_size, direction, self.normalize_t)
+        out = out[..., : ev.shape[-1]]
+        return like_input(out, events), skip_feature()
+
+    def calculate_reftime(self, events: NUMPY_TORCH, direction: Union[str, float] = "first") -> FLOAT_TORCH:
+        """Reference time of the warp (src/warp.py:201-233)."""
+        t = events[..., 2]
+        if type(direction) is float:
+            lo = nt_min(t, -1)
+            return lo + (nt_max(t, -1) - lo) * direction
+        if direction == "first":
+            return nt_min(t, -1)
+        if direction == "last":
+            return nt_max(t, -1)
+        if direction == "middle":
+            return self.calculate_reftime(events, 0.5)
+        if direction == "random":
+            return self.calculate_reftime(events, float(np.random.uniform(low=0.0, high=1.0)))
+        if direction == "before":
+            return self.calculate_reftime(events, -1.0)
+        if direction == "after":
+            return self.calculate_reftime(events, 2.0)
+        e = f"direction argument should be first, middle, last. Or float. {direction}"
+        logger.error(e)
+        raise ValueError(e)
+
+    def calculate_dt(self, event: NUMPY_TORCH, reference_time: FLOAT_TORCH,
+                     time_period: Optional[FLOAT_TORCH] = None) -> NUMPY_TORCH:
+        """dt = t - reference_time, divided by the batch period when normalize_t (src/warp.py:235-259)."""
+        dt = event[..., 2] - reference_time
+        if self.normalize_t:
+            if time_period is None:
+                time_period = nt_max(dt, -1) - nt_min(dt, -1)
+            dt = dt / (time_period[..., None] if hasattr(time_period, "shape") and len(time_period.shape) > 0 else time_period)
+        return dt

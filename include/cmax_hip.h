@@ -1,0 +1,242 @@
+/*
+ * cmax_hip.h -- C ABI of libcmax_hip.so: the MI355X (gfx950) contrast-maximization inner loop
+ * (event warp -> image of warped events -> contrast objective + analytic gradient).
+ *
+ * The reference (tub-rip/event_based_optical_flow) is pure Python and has NO FFI; its "plugin API"
+ * for this path is three Python classes.  Each entry point below names the
+ * reference function it replaces (file:line relative to the reference root); the Python host
+ * layer in event_based_optical_flow_amd/ mirrors those classes and calls this ABI through ctypes.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every function returns int: 0 ok, <0 bad argument (CMAX_E*), >0 a hipError_t.
+ *    cmax_last_error() returns a thread-local description of the last failure.
+ *  - all pointers are DEVICE pointers borrowed from the caller (PyTorch's allocator) unless the
+ *    name ends in _host; nothing is retained after the call returns except by cmax_set_events.
+ *  - work is enqueued on `stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ *    no entry point synchronises the device.
+ *  - events are row-major [n,4] = (x, y, t, p); x is the ROW coordinate, y the COLUMN
+ *    (src/event_image_converter.py:344-345); images are row-major [H, W].
+ *  - dtype: CMAX_F32 or CMAX_F64 (leaf ops compute in the dtype of their inputs, like the reference,
+ *    whose outputs follow the events' dtype, src/event_image_converter.py:338).
+ */
+#ifndef CMAX_HIP_H
+#define CMAX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMAX_ABI_VERSION 1
+
+/* dtypes */
+#define CMAX_F32 0
+#define CMAX_F64 1
+
+/* motion models -- Warp.warp_event dispatcher, src/warp.py:156-199 */
+#define CMAX_MODEL_2DOF 0  /* "2d-translation", "rigid-optical-flow"  src/warp.py:483-522 */
+#define CMAX_MODEL_DENSE 1 /* "dense-flow"                            src/warp.py:263-313 */
+#define CMAX_MODEL_VOXEL 2 /* "dense-flow-voxel"                      src/warp.py:315-396 */
+
+/* reference-time modes -- Warp.calculate_reftime, src/warp.py:201-233 */
+#define CMAX_REF_FIRST 0 /* t_min exactly */
+#define CMAX_REF_LAST 1  /* t_max exactly */
+#define CMAX_REF_FRAC 2  /* t_min + (t_max - t_min) * frac ("middle" = 0.5, "before" = -1, "after" = 2) */
+
+/* contrast functions */
+#define CMAX_COST_VARIANCE 0 /* ImageVariance      src/costs/image_variance.py:27-71 */
+#define CMAX_COST_GRADMAG 1  /* GradientMagnitude  src/costs/gradient_magnitude.py:60-76 */
+
+/* flow propagation schemes -- src/utils/flow_utils.py */
+#define CMAX_SCHEME_BURGERS 0 /* inviscid_burger_flow_to_voxel_torch  567-639 */
+#define CMAX_SCHEME_UPWIND 1  /* upwind_flow_to_voxel_torch           439-493 */
+
+/* error codes */
+#define CMAX_EINVAL -1   /* bad argument */
+#define CMAX_ENOMEM -2   /* workspace allocation failed */
+#define CMAX_ESTATE -3   /* call order (e.g. objective before set_events) */
+#define CMAX_ENODEV -4   /* no usable gfx950 device */
+
+typedef void *cmax_stream_t; /* hipStream_t */
+typedef struct cmax_handle_s *cmax_handle_t;
+
+const char *cmax_last_error(void);
+int cmax_abi_version(void);
+
+/* =============================================================================================
+ * Leaf operators (stateless).  One per reference leaf function; dtype-generic.
+ * ============================================================================================= */
+
+/* min / max of the event timestamps -> tminmax[2] (device doubles).
+ * Replaces nt_min / nt_max over events[..., 2] in Warp.calculate_reftime (src/warp.py:216-224). */
+int cmax_tminmax(const void *events, int dtype, int64_t n, double *tminmax, cmax_stream_t stream);
+
+/* Warp.warp_event (src/warp.py:156-199) incl. calculate_reftime (201-233) and calculate_dt
+ * (235-259): warped[n,4] = (x', y', dt, p).
+ *   ref_mode/ref_frac : reference time (CMAX_REF_*), evaluated on the device from tminmax[2]
+ *   normalize_t       : dt /= (max(dt) - min(dt))            (src/warp.py:254-259)
+ *   motion            : theta[2] | flow[2,H,W] | voxel[T,2,H,W], same dtype as events
+ *   dt_out            : optional [n] copy of dt (saved for the backward pass)
+ *   bin_out           : optional int32[n], voxel model only: time bin per event (-1 = none)  */
+int cmax_warp_events(const void *events, int dtype, int64_t n, int model, const void *motion, int T,
+                     int H, int W, const double *tminmax, int ref_mode, double ref_frac,
+                     int normalize_t, void *warped, void *dt_out, int32_t *bin_out,
+                     cmax_stream_t stream);
+
+/* adjoint of cmax_warp_events w.r.t. the motion (what torch autograd derives for warp.py:304-307,
+ * 357-362, 506-520): given gwarped[n,4] (only columns 0,1 are read)
+ *   2DOF : gmotion[2]        = sum_e dt_e * (gx_e, gy_e)        (dtype, overwritten)
+ *   DENSE: gmotion[2,H,W]   += -dt_e * g_e at the source pixel  (zeroed inside)
+ *   VOXEL: gmotion[T,2,H,W] likewise into bin(e)                                            */
+int cmax_warp_events_bwd(const void *events, int dtype, int64_t n, int model, int T, int H, int W,
+                         const void *dt, const int32_t *bin, const void *gwarped, void *gmotion,
+                         cmax_stream_t stream);
+
+/* EventImageConverter.bilinear_vote_tensor / count_event_tensor
+ * (src/event_image_converter.py:316-374, 209-255).
+ *   xy      : pointer to x' of event 0; `stride` elements between events (4 for an [n,4] array)
+ *   weight  : optional per-event weight [n]; else the scalar `wscalar`   (330-331)
+ *   Hp, Wp  : PADDED image size; ph, pw: padding offsets                  (28, 344-345)
+ *   eps     : 1e-6 (torch branch, 340) or 1e-8 (numpy branch, 282)
+ *   count   : !=0 -> every in-bounds corner += 1                          (251-254)
+ *   img     : [Hp,Wp], overwritten                                                          */
+int cmax_vote(const void *xy, int dtype, int64_t stride, int64_t n, const void *weight,
+              double wscalar, int Hp, int Wp, int ph, int pw, double eps, int count, void *img,
+              cmax_stream_t stream);
+
+/* adjoint of cmax_vote (autograd of scatter_add_ = gather; floor has zero derivative):
+ *   gxy[n,2] = (dL/dx', dL/dy'),  gw[n] = dL/dweight (optional).  G is [Hp,Wp].             */
+int cmax_vote_bwd(const void *xy, int dtype, int64_t stride, int64_t n, const void *weight,
+                  double wscalar, int Hp, int Wp, int ph, int pw, double eps, const void *G,
+                  void *gxy, void *gw, cmax_stream_t stream);
+
+/* Gaussian blur of create_image_from_events_tensor (src/event_image_converter.py:153-159):
+ * 3 taps exp(-0.5 (k/sigma)^2) normalised, reflect-101 padding, separable.  adjoint != 0 applies
+ * the transposed operator (backward pass).  in != out.                                       */
+int cmax_blur3(const void *in, int dtype, int H, int W, double sigma, int adjoint, void *out,
+               cmax_stream_t stream);
+
+/* ImageVariance.calculate / GradientMagnitude.calculate (src/costs/image_variance.py:27-71,
+ * src/costs/gradient_magnitude.py:60-76 + SobelTorch src/utils/stat_utils.py:50-83).
+ *   value  : device double[4]: value[0] = the RAW contrast (no sign), value[1..3] = scratch
+ *            accumulators (zeroed inside); ddof 1 = torch.var, 0 = np.var
+ *   G      : optional [H,W] = gscale * d value / d img, gscale read from the device double
+ *            `gscale` (NULL = 1) -- lets the caller chain the upstream gradient on the device */
+int cmax_contrast(const void *img, int dtype, int H, int W, int cost, int omit_boundary, int ddof,
+                  double *value, void *G, const double *gscale, cmax_stream_t stream);
+
+/* TotalVariation.calculate_torch (src/costs/total_variation.py:60-75, 110-126): flow [2,h,w];
+ * value is a device double[4] as for cmax_contrast.                                           */
+int cmax_total_variation(const void *flow, int dtype, int h, int w, int omit_boundary,
+                         double *value, void *G, const double *gscale, cmax_stream_t stream);
+
+/* One propagation step (src/utils/flow_utils.py:567-639 / 439-493) on F[2,H,W] and its adjoint
+ * (gF += J^T gout).                                                                          */
+int cmax_flow_step(const void *F, int dtype, int H, int W, double dt, int scheme, void *out,
+                   cmax_stream_t stream);
+int cmax_flow_step_adj(const void *F, int dtype, int H, int W, double dt, int scheme,
+                       const void *gout, void *gF, cmax_stream_t stream);
+
+/* construct_dense_flow_voxel_torch (src/utils/flow_utils.py:99-161): V[T,2,H,W] from F at bin
+ * t0 (0 = "first", T/2 = "middle"); and its adjoint (gV is clobbered, gF[2,H,W] overwritten).  */
+int cmax_voxel_construct(const void *F, int dtype, int T, int t0, int H, int W, int scheme, void *V,
+                         cmax_stream_t stream);
+int cmax_voxel_construct_adj(const void *V, int dtype, int T, int t0, int H, int W, int scheme,
+                             void *gV, void *gF, cmax_stream_t stream);
+
+/* =============================================================================================
+ * Fused objective (the hot path): events are packed + sorted once per batch, then every
+ * evaluation runs  warp+vote -> contrast -> gather-gradient  without materialising warped events.
+ * Replaces one pass of PatchContrastMaximization.get_arg_for_cost + cost.calculate +
+ * torch.autograd.grad (src/solver/patch_contrast_base.py:273-352,
+ * src/solver/scipy_autograd/torch_wrapper.py:30-49).  Arithmetic: fp32 per event, fp64 reductions.
+ * ============================================================================================= */
+
+/* H, W: un-padded sensor size; ph, pw: outer padding (image is [H+2ph, W+2pw]).               */
+int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out);
+int cmax_destroy(cmax_handle_t h);
+
+/* Pack (12-bit row | 12-bit col | 8-bit time bin ; fp32 normalised time ; optional fractional
+ * residuals) and counting-sort the batch by source-pixel tile.  events: [n,4] dtype.
+ * If have_tminmax, (tmin, tmax) are the GLOBAL batch extremes (multi-GPU time slices);
+ * otherwise they are reduced from this call's events.  n_time_bin > 0 precomputes the voxel
+ * bin of every event with the reference's fp64 edge arithmetic (src/warp.py:342-345).        */
+int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, int have_tminmax,
+                    double tmin, double tmax, int n_time_bin, cmax_stream_t stream);
+int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream);
+
+/* Image of warped events for one reference time (fp32 [Hp,Wp], blurred if sigma > 0).
+ * motion: fp32 theta[2] | flow[2,H,W] | voxel[T,2,H,W] in pixel per (normalised) time.
+ * model < 0 builds the un-warped image ("orig_iwe", patch_contrast_base.py:295-301).          */
+int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac,
+             int normalize_t, double sigma, float *iwe_out, cmax_stream_t stream);
+
+/* Objective descriptor.  loss = sum_k mult_k * term(v_k) over the listed reference times, with
+ *   normalized == 0 : term = sign * v_k                      (ImageVariance / GradientMagnitude,
+ *                                                              sign = -1 for "minimize")
+ *   normalized == 1 : term = v_orig / v_k  ("minimize")       (normalized_*.py, multi_focal_*.py)
+ *                     or v_k / v_orig      (otherwise)
+ * v = raw contrast (cost, omit_boundary) of the (blurred) IWE; v_orig of the un-warped IWE
+ * (NOT boundary-cropped for the variance, normalized_image_variance.py:40-41).                */
+typedef struct {
+    int32_t model;        /* CMAX_MODEL_* */
+    int32_t cost;         /* CMAX_COST_* */
+    int32_t normalized;   /* 0 / 1 */
+    int32_t minimize;     /* 1 = direction "minimize", 0 = "natural"/"maximize" value */
+    int32_t negate;       /* 1 = return -loss (multi_focal_* with direction "maximize") */
+    int32_t omit_boundary;
+    int32_t normalize_t;
+    int32_t n_ref;        /* 1..4 reference times */
+    int32_t ref_mode[4];  /* CMAX_REF_* */
+    double ref_frac[4];
+    double mult[4];       /* e.g. forward 1, backward 1, middle 2 */
+    double sigma;         /* blur (0 = none) */
+    int32_t T;            /* voxel time bins */
+    int32_t reserved;
+} cmax_objective_t;
+
+/* One evaluation.  result[0] = loss, result[1..n_ref] = v_k, result[5] = v_orig (device
+ * doubles, result has 8 entries).  grad: fp64 [2] for 2DOF, fp32 [2,H,W] / [T,2,H,W] otherwise
+ * (overwritten); NULL skips the gradient pass.                                               */
+int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+                   double *result, void *grad, cmax_stream_t stream);
+
+/* Phase-split form for time-sliced multi-GPU runs (one handle per GPU, each holding a contiguous
+ * time slice of the batch and the GLOBAL tmin/tmax):
+ *   cmax_objective_vote    raw votes of this slice: images[k] for k < n_ref, plus images[n_ref] =
+ *                          the un-warped image when a normalised cost needs it and it is not cached;
+ *                          *n_images_host = number of images written (n_ref or n_ref + 1)
+ *   -- caller all-reduces (sum) images[0 .. n_images) across GPUs (RCCL) --
+ *   cmax_objective_finish  blur, contrast statistics, loss (identical on every GPU), then the
+ *                          gradient contribution of THIS slice's events
+ *   -- caller all-reduces (sum) grad --
+ * images: fp32 [5, Hp, Wp] caller-owned.  cmax_objective == vote + finish on internal images.  */
+int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+                        float *images, int *n_images_host, cmax_stream_t stream);
+int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+                          const float *images, int n_images, double *result, void *grad,
+                          cmax_stream_t stream);
+
+/* Per-kernel-class timing for bench.py's roofline: when enabled every launch of the four hot kernels
+ * is bracketed by HIP events ON THE LAUNCH STREAM.  cmax_read_profile synchronises on them, returns
+ * total milliseconds and launch counts for class 0 = K1 warp+vote, 1 = K2 contrast statistics,
+ * 2 = K2b gradient image, 3 = K3 per-event gradient (host arrays of 4), and resets.           */
+int cmax_set_profiling(cmax_handle_t h, int enable);
+int cmax_read_profile(cmax_handle_t h, double *total_ms_host, int64_t *count_host);
+
+/* sizeof(cmax_objective_t) as compiled into the library (binding self-check).                 */
+int cmax_sizeof_objective(void);
+
+/* Copy the fp32 IWE [Hp,Wp] of reference time k of the last cmax_objective call (the image the
+ * contrast was evaluated on, i.e. blurred when sigma > 0) into iwe_out, on `stream`.          */
+int cmax_copy_iwe(cmax_handle_t h, int k, float *iwe_out, cmax_stream_t stream);
+
+/* Introspection for tests / bench: number of packed events, HBM bytes held by the handle.     */
+int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMAX_HIP_H */

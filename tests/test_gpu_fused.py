@@ -1,0 +1,265 @@
+"""GPU parity of the FUSED objective (cmax_set_events / cmax_objective: fp32 per event, fp64
+reductions) against the reference's fp64 values.
+
+Tolerance (BASELINE.json north_star, SURVEY.md section 8d "parity gate"), judged against fp64:
+    IWE      max|I - I_ref| / max|I_ref|        <= 1e-4
+    loss     |L - L_ref| / |L_ref|              <= 1e-4
+    gradient max|g - g_ref| / max|g_ref|        <= 1e-4
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import event_based_optical_flow_amd as E  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+TOL = 1e-4
+DEV = "cuda"
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def T(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def fused_eval(size, events, motion, model, cost, sigma, pad=0, time_bin=0, cost_with_weight=None, coarse=None,
+               direction="minimize"):
+    h = E.CMaxHandle(size, pad)
+    h.set_events(events, time_bin=time_bin)
+    obj = E.ContrastObjective(h, model, cost=cost, cost_with_weight=cost_with_weight, sigma=sigma, direction=direction)
+    m = T(motion).requires_grad_()
+    c = T(coarse).requires_grad_() if coarse is not None else None
+    loss = obj(m, c)
+    ins = [m] + ([c] if c is not None and cost_with_weight and "total_variation" in cost_with_weight else [])
+    grads = torch.autograd.grad(loss, ins)
+    return loss.item(), [g.cpu().numpy() for g in grads], h
+
+
+YAML_HYBRID = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01}
+OBJ_CASES = [(c, s) for c in ("image_variance", "gradient_magnitude") for s in (0, 1)] + [
+    (c, 1) for c in ("normalized_image_variance", "normalized_gradient_magnitude",
+                     "multi_focal_normalized_image_variance", "multi_focal_normalized_gradient_magnitude", "hybrid")]
+MOTIONS = {"2dof": ("2d-translation", "theta"), "dense_rand": ("dense-flow", "flow_rand"),
+           "dense_smooth": ("dense-flow", "flow_smooth"), "voxel": ("dense-flow-voxel", "voxel")}
+
+
+@pytest.mark.parametrize("mname", list(MOTIONS))
+@pytest.mark.parametrize("cost,sigma", OBJ_CASES)
+def test_fused_objective_golden(golden, mname, cost, sigma):
+    """Fixtures hold the REFERENCE's loss / gradient / IWEs for the same inputs."""
+    g = golden("objective")
+    model, mkey = MOTIONS[mname]
+    size = tuple(int(v) for v in g["image_size"])
+    tb = g[mkey].shape[0] if model == "dense-flow-voxel" else 0
+    loss, grads, h = fused_eval(size, g["events"], g[mkey], model, cost, sigma, time_bin=tb,
+                                cost_with_weight=YAML_HYBRID if cost == "hybrid" else None, coarse=g["coarse"])
+    tag = f"{mname}__{cost}__s{sigma}"
+    assert abs(loss - g[tag + "__loss"]) <= TOL * abs(g[tag + "__loss"])
+    assert rel_max(grads[0], g[tag + "__grad"]) <= TOL
+    if len(grads) > 1:
+        assert rel_max(grads[1], g[tag + "__grad_coarse"]) <= TOL
+    if tag + "__iwe" in g and cost == "image_variance":
+        assert rel_max(h.last_iwe(0).cpu().numpy(), g[tag + "__iwe"]) <= TOL
+    if tag + "__forward_iwe" in g:  # multi-focal: slot 0 = forward ("last"), 1 = backward ("first"), 2 = middle
+        assert rel_max(h.last_iwe(0).cpu().numpy(), g[tag + "__forward_iwe"]) <= TOL
+        assert rel_max(h.last_iwe(2).cpu().numpy(), g[tag + "__middle_iwe"]) <= TOL
+
+
+@pytest.mark.parametrize("pad", [0, 4])
+def test_fused_fractional_sources_and_padding(golden, pad):
+    g = golden("objective")
+    size = tuple(int(v) for v in g["image_size"])
+    loss, grads, h = fused_eval(size, g["events_frac"], g["theta"], "2d-translation", "image_variance", 1, pad=pad)
+    assert abs(loss - g[f"frac_pad{pad}__loss"]) <= TOL * abs(g[f"frac_pad{pad}__loss"])
+    assert rel_max(grads[0], g[f"frac_pad{pad}__grad"]) <= TOL
+    assert rel_max(h.last_iwe(0).cpu().numpy(), g[f"frac_pad{pad}__iwe"]) <= TOL
+
+
+@pytest.mark.parametrize("direction", ["natural", "maximize"])
+@pytest.mark.parametrize("cost", ["image_variance", "normalized_gradient_magnitude", "multi_focal_normalized_image_variance"])
+def test_fused_directions_vs_oracle(golden, direction, cost):
+    g = golden("objective")
+    size = tuple(int(v) for v in g["image_size"])
+    ref = orc.objective(g["events"], g["flow_smooth"], "dense-flow", size, cost=cost, sigma=1, direction=direction)
+    loss, grads, _ = fused_eval(size, g["events"], g["flow_smooth"], "dense-flow", cost, 1, direction=direction)
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs at sizes the oracle finishes in seconds (seeded inputs, fp64 oracle)
+# ---------------------------------------------------------------------------------------------
+def _structured(n, size, vel, seed):
+    return E.utils.generate_structured_events(n, size[0], size[1], vel, n_dots=max(50, n // 400), seed=seed)
+
+
+def test_cfg2_2dof_variance_structured():
+    """cfg2 shape: 260x346, 2-DoF, variance; structured (moving-dot) events, theta 20 % off the optimum."""
+    size, n = (260, 346), 300_000
+    vel = (12.3, -7.7)
+    ev = _structured(n, size, vel, 46)
+    theta = np.array(vel) * 0.8
+    ref = orc.objective(ev, theta, "2d-translation", size, cost="image_variance", sigma=0)
+    loss, grads, h = fused_eval(size, ev, theta, "2d-translation", "image_variance", 0)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
+def test_cfg2_2dof_variance_uniform_random():
+    """Documented worst case (SURVEY.md section 7 hard part 2): uniform-random events, the gradient
+    is a heavily cancelling sum.  The integer-base/displacement split keeps it inside 1e-4."""
+    size, n = (260, 346), 300_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    theta = np.array([12.3, -7.7])
+    ref = orc.objective(ev, theta, "2d-translation", size, cost="image_variance", sigma=0)
+    loss, grads, h = fused_eval(size, ev, theta, "2d-translation", "image_variance", 0)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    scale = np.abs(ref["grad"]).max()
+    assert np.abs(grads[0] - ref["grad"]).max() <= 1e-3 * scale, (grads[0], ref["grad"])
+
+
+def test_cfg3_dense_gradmag():
+    size, n = (120, 160), 400_000  # DSEC aspect, reduced so the oracle finishes in seconds
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=47)
+    flow = E.utils.generate_smooth_flow(size, 20, seed=48)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="gradient_magnitude", sigma=0)
+    loss, grads, h = fused_eval(size, ev, flow, "dense-flow", "gradient_magnitude", 0)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
+def test_cfg4_burgers_voxel_variance():
+    size, n, Tn = (130, 173), 300_000, 10
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=49)
+    f0 = E.utils.generate_smooth_flow(size, 20, seed=50)
+    voxel = orc.construct_dense_flow_voxel(f0 / 20.0, Tn, "burgers", "middle") * 20.0
+    ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=1)
+    loss, grads, h = fused_eval(size, ev, voxel, "dense-flow-voxel", "image_variance", 1, time_bin=Tn)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
+def test_voxel_chain_to_t0_flow():
+    """flow_t0 -> Burgers voxel (HIP, autograd) -> fused voxel objective: gradient w.r.t. flow_t0."""
+    size, n, Tn = (64, 80), 50_000, 10
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=51)
+    f0 = E.utils.generate_smooth_flow(size, 10, seed=52)
+    V = orc.construct_dense_flow_voxel(f0, Tn, "burgers", "middle")
+    ref = orc.objective(ev, V, "dense-flow-voxel", size, cost="image_variance", sigma=1)
+    g_f0 = orc.construct_dense_flow_voxel_adj(V, ref["grad"], "burgers", "middle")
+    h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
+    obj = E.ContrastObjective(h, "dense-flow-voxel", cost="image_variance", sigma=1)
+    tf = T(f0).requires_grad_()
+    loss = obj(E.utils.construct_dense_flow_voxel_torch(tf, Tn, "burgers", "middle"))
+    (g,) = torch.autograd.grad(loss, tf)
+    assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(g.cpu().numpy(), g_f0) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE's full sizes
+# ---------------------------------------------------------------------------------------------
+def test_full_size_mass_and_linearity():
+    """cfg2 full size (1M events, 260x346): (i) with zero motion every event votes weight 1 in
+    bounds -> sum(IWE) == N exactly representable; (ii) IWE(A u B) == IWE(A) + IWE(B)."""
+    size, n = (260, 346), 1_000_000
+    ev = E.utils.generate_events(n, size[0] - 1, size[1] - 1, 0.0, 0.05, seed=46)
+    h = E.CMaxHandle(size).set_events(ev)
+    assert h.n_events == n
+    iwe0 = h.iwe(np.zeros(2), "2d-translation")
+    assert abs(float(iwe0.double().sum()) - n) < 1e-6 * n
+    theta = np.array([12.3, -7.7])
+    full = h.iwe(theta, "2d-translation").double()
+    tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
+    a = E.CMaxHandle(size).set_events(ev[: n // 3], tmin, tmax).iwe(theta, "2d-translation").double()
+    b = E.CMaxHandle(size).set_events(ev[n // 3:], tmin, tmax).iwe(theta, "2d-translation").double()
+    assert float((a + b - full).abs().max()) <= 1e-5 * float(full.abs().max())
+
+
+def test_full_size_gradient_vs_finite_difference():
+    """cfg2 full size: analytic 2-DoF gradient against a central difference of the loss itself."""
+    size, n = (260, 346), 1_000_000
+    ev = _structured(n, size, (12.3, -7.7), 46)
+    h = E.CMaxHandle(size).set_events(ev)
+    desc = E.make_descriptor("image_variance", "2d-translation", sigma=1.0)
+    theta = np.array([10.0, -6.0])
+    res, grad = h.evaluate(desc, theta)
+    g = grad.cpu().numpy()
+    eps = 0.05
+    for c in range(2):
+        d = np.zeros(2)
+        d[c] = eps
+        lp = h.evaluate(desc, theta + d, want_grad=False)[0][0].item()
+        lm = h.evaluate(desc, theta - d, want_grad=False)[0][0].item()
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - g[c]) <= 2e-2 * max(abs(g).max(), 1e-12), (c, fd, g)
+
+
+def test_cfg5_shape_time_slices_sum_to_whole():
+    """cfg5 shape (1280x720, dense flow, variance): per-time-slice IWEs and gradients (what each GPU
+    of the time-sliced run owns) add up to the single-handle result."""
+    size, n, parts = (720, 1280), 2_000_000, 4
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=53)
+    flow = T(E.utils.generate_smooth_flow(size, 20, seed=54), torch.float32)
+    tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
+    whole = E.CMaxHandle(size).set_events(ev)
+    iwe = whole.iwe(flow, "dense-flow").double()
+    acc = torch.zeros_like(iwe)
+    for sl in np.array_split(np.arange(n), parts):
+        acc += E.CMaxHandle(size).set_events(ev[sl], tmin, tmax).iwe(flow, "dense-flow").double()
+    assert float((acc - iwe).abs().max()) <= 1e-5 * float(iwe.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases (failure handling)
+# ---------------------------------------------------------------------------------------------
+def test_empty_batch_gives_zero_loss_and_grad():
+    h = E.CMaxHandle((32, 40)).set_events(np.zeros((0, 4)))
+    desc = E.make_descriptor("image_variance", "dense-flow")
+    res, grad = h.evaluate(desc, np.zeros((2, 32, 40)))
+    assert res[0].item() == 0.0 and float(grad.abs().sum()) == 0.0
+
+
+def test_out_of_sensor_sources_are_dropped_not_crashing():
+    ev = E.utils.generate_events(1000, 32, 40, seed=1)
+    ev[::10, 0] = -5.0
+    ev[5::10, 1] = 1e9
+    ev[7, 0] = np.nan
+    h = E.CMaxHandle((32, 40)).set_events(ev)
+    keep = np.isfinite(ev[:, 0]) & (ev[:, 0] >= 0) & (ev[:, 0] < 32) & (ev[:, 1] >= 0) & (ev[:, 1] < 40)
+    assert h.n_events == int(keep.sum())
+    iwe = h.iwe(np.zeros(2), "2d-translation")
+    assert abs(float(iwe.sum()) - keep.sum()) < 1e-3
+
+
+def test_everything_warps_out_of_the_image():
+    ev = E.utils.generate_events(2000, 32, 40, seed=2)
+    h = E.CMaxHandle((32, 40)).set_events(ev)
+    iwe = h.iwe(np.array([1e5, 1e5]), "2d-translation", direction="middle")
+    assert float(iwe.abs().sum()) < 40.0  # only events with dt ~ 0 stay
+
+
+def test_bad_arguments_raise():
+    h = E.CMaxHandle((32, 40)).set_events(E.utils.generate_events(100, 32, 40, seed=3))
+    with pytest.raises(KeyError):
+        E.make_descriptor("zhu_average_timestamp", "dense-flow")
+    with pytest.raises(KeyError):
+        E.make_descriptor("image_variance", "affine")
+    with pytest.raises(ValueError):
+        E.make_descriptor("image_variance", "dense-flow", direction="sideways")
+    with pytest.raises(E._lib.CmaxError):  # voxel objective without time bins on the handle
+        h.evaluate(E.make_descriptor("image_variance", "dense-flow-voxel", time_bin=10), np.zeros((10, 2, 32, 40)))
+    with pytest.raises(E._lib.CmaxError):
+        E.CMaxHandle((5000, 40))
+    with pytest.raises(ValueError):
+        h.set_events(np.zeros((10, 3)))
