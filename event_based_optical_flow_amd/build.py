@@ -5,7 +5,8 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libcmax_hip.so")
+# CMAX_LIB: alternative output / load path (tuning experiments build variants side by side)
+LIB_PATH = os.environ.get("CMAX_LIB", os.path.join(PKG_DIR, "libcmax_hip.so"))
 SOURCES = ["cmax_leaf.hip", "cmax_flow.hip", "cmax_fused.hip"]
 HEADERS = ["cmax_common.h", "cmax_image_kernels.h", os.path.join("..", "..", "include", "cmax_hip.h")]
 # -munsafe-fp-atomics: fp32/fp64 atomicAdd lower to global_atomic_add_f32/_f64 and ds_add_f32
@@ -32,7 +33,8 @@ def needs_build() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+    extra = os.environ.get("CMAX_EXTRA_FLAGS", "").split()
+    cmd = [hipcc_path()] + HIPCC_FLAGS + extra + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

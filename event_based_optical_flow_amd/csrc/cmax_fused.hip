@@ -26,16 +26,23 @@ namespace cmax {
 
 constexpr int kTile = 16;  // source-pixel tile edge of the counting sort
 constexpr uint32_t kDropped = 0xFFFFFFFFu;
-constexpr int kEPT = 8;                       // events per thread (cached in registers between the two phases)
-constexpr int kSegMax = 2040;                 // events per segment: |sum of votes| < 2040 * 2^20 < 2^31
-constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit words (32 KiB)
+#ifndef CMAX_EPT
+#define CMAX_EPT 8
+#endif
+#ifndef CMAX_WINCAP
+#define CMAX_WINCAP 8192
+#endif
+constexpr int kEPT = CMAX_EPT;                // events per thread (cached in registers between the two phases)
+constexpr int kSegMax = 256 * kEPT - 8;       // events per segment (+1 for the even-aligned start still fits 256*kEPT);
+                                              // |sum of votes| <= 2040 * 2^20 < 2^31
+constexpr int kWinCap = CMAX_WINCAP;          // LDS window capacity in 32-bit words (32 KiB)
+static_assert(kSegMax <= 2040, "fixed-point vote accumulation would overflow");
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
 constexpr float kFix = 1048576.f;             // 2^20: votes are accumulated as signed 12.20 fixed point
 constexpr float kInvFix = 1.f / 1048576.f;
 
 struct EvView {
-    const uint32_t *xyb;  // row | col << 12 | bin << 24
-    const float *tau;     // (t - tmin) / (tmax - tmin)
+    const uint2 *ev;      // .x = row | col << 12 | bin << 24 ; .y = bits of fp32 tau = (t - tmin) / (tmax - tmin)
     const float *rx;      // fractional residual of the source coordinate (nullptr if integral)
     const float *ry;
     int64_t n;
@@ -59,8 +66,8 @@ struct cmax_handle_s {
     bool has_frac = false;
     int n_time_bin = 0;
     // packed, sorted events
-    uint32_t *xyb = nullptr;
-    float *tau = nullptr, *rx = nullptr, *ry = nullptr;
+    uint2 *evp = nullptr;  // packed events, 8 B each, 16-byte aligned base (+2 elements of padding)
+    float *rx = nullptr, *ry = nullptr;
     double *tau64 = nullptr;
     // sort scratch
     uint32_t *key_tmp = nullptr;
@@ -72,13 +79,17 @@ struct cmax_handle_s {
     int2 *d_segs = nullptr;       // [nseg] (begin, count) work items of the event kernels
     int nseg = 0, seg_cap = 0;
     // images
-    float *imgs = nullptr;                                  // [5, Hp, Wp] raw votes: one per reference time + un-warped
+    float *imgs = nullptr;                                  // [2 buffers][5, Hp, Wp] raw votes: one per reference time + un-warped
     float *iweb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // blurred copies
     float *G = nullptr, *Gt = nullptr;
     const float *last_iwe[4] = {nullptr, nullptr, nullptr, nullptr};
     // device scalars
     double *d_tmm = nullptr;  // [2]
-    double *d_part = nullptr;   // [5 slots][256 workgroups][2] contrast-statistics partials (slot 4 = un-warped image)
+    double *d_stat = nullptr;   // [5 slots][8 sub-accumulators][2] contrast statistics (slot 4 = un-warped image)
+    // the handle's own vote images are double-buffered: k_stats of evaluation e zeroes the images of
+    // evaluation e+1, so the steady state needs no memset node.  zero_mask[b] bit k: image k of buffer b is zero
+    int cur_buf = 0;
+    unsigned zero_mask[2] = {0u, 0u};
     double *d_gpart = nullptr;  // [4 reference times][nseg][2] per-segment 2-DoF gradient partials
     // orig-IWE cache key
     bool orig_valid = false;
@@ -207,8 +218,8 @@ __global__ void __launch_bounds__(1024) k_scan(int *__restrict__ counts, int m) 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_scatter(const T *__restrict__ ev, int64_t n, const uint32_t *__restrict__ key, const int *__restrict__ offsets,
-          int *__restrict__ cursor, const double *__restrict__ tmm, int n_time_bin, uint32_t *__restrict__ xyb,
-          float *__restrict__ tau, float *__restrict__ rx, float *__restrict__ ry, double *__restrict__ tau64) {
+          int *__restrict__ cursor, const double *__restrict__ tmm, int n_time_bin, uint2 *__restrict__ evp,
+          float *__restrict__ rx, float *__restrict__ ry, double *__restrict__ tau64) {
     const double tmin = tmm[0], per = tmm[1] - tmm[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t k = key[i];
@@ -218,8 +229,7 @@ k_scatter(const T *__restrict__ ev, int64_t n, const uint32_t *__restrict__ key,
         T fx = floor_t<T>(x), fy = floor_t<T>(y);
         double tn = per > 0 ? ((double)ev[4 * i + 2] - tmin) / per : 0.0;
         uint32_t bin = n_time_bin > 0 ? (uint32_t)voxel_bin(tn, n_time_bin) : 0u;
-        xyb[pos] = (uint32_t)(int)fx | ((uint32_t)(int)fy << 12) | (bin << 24);
-        tau[pos] = (float)tn;
+        evp[pos] = make_uint2((uint32_t)(int)fx | ((uint32_t)(int)fy << 12) | (bin << 24), __float_as_uint((float)tn));
         rx[pos] = (float)(x - fx);
         ry[pos] = (float)(y - fy);
         tau64[pos] = tn;
@@ -232,10 +242,10 @@ __global__ void __launch_bounds__(256) k_tile_starts(const int *__restrict__ off
     if (t <= ntiles) tile_start[t] = offsets[t * (kTile * kTile)];
 }
 
-__global__ void __launch_bounds__(256) k_rebin(int64_t n, const double *__restrict__ tau64, int n_time_bin, uint32_t *__restrict__ xyb) {
+__global__ void __launch_bounds__(256) k_rebin(int64_t n, const double *__restrict__ tau64, int n_time_bin, uint2 *__restrict__ evp) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t bin = n_time_bin > 0 ? (uint32_t)voxel_bin(tau64[i], n_time_bin) : 0u;
-        xyb[i] = (xyb[i] & 0x00FFFFFFu) | (bin << 24);
+        evp[i].x = (evp[i].x & 0x00FFFFFFu) | (bin << 24);
     }
 }
 
@@ -251,11 +261,11 @@ struct Warped {
 
 // MODEL: -1 none (orig_iwe), 0 2-DoF, 1 dense, 2 voxel
 template <int MODEL, bool FRAC>
-__device__ __forceinline__ Warped warp_one(const EvView &ev, int64_t i, const WarpParams &wp, float tscale, float th0, float th1) {
+__device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i, const WarpParams &wp, float tscale, float th0, float th1) {
     Warped w;
-    const uint32_t pk = ev.xyb[i];
+    const uint32_t pk = e.x;
     const int ix = (int)(pk & 0xFFFu), iy = (int)((pk >> 12) & 0xFFFu);
-    w.dt = (ev.tau[i] - wp.d) * tscale;  // calculate_dt, src/warp.py:254-259
+    w.dt = (__uint_as_float(e.y) - wp.d) * tscale;  // calculate_dt, src/warp.py:254-259
     float dx = FRAC ? ev.rx[i] : 0.f, dy = FRAC ? ev.ry[i] : 0.f;
     w.src = ix * wp.W + iy;
     if (MODEL == CMAX_MODEL_2DOF) {
@@ -292,7 +302,10 @@ __device__ __forceinline__ int segment_of_block(int nseg) {
 
 struct Window {
     int r0, c0, h, w;  // top-left corner in the padded image, extent (clipped to the image and to LDS)
+    int sh;            // LDS row stride = 1 << sh (power of two: a shift instead of an integer multiply per vote)
+    bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
 };
+constexpr int kDummy = kWinCap;  // 64 scratch words behind the window: target of masked lanes (branch-free phase B)
 
 // Phase A of both event kernels: warp this thread's <= kEPT events (kept in registers), reduce the
 // bounding box of their 2x2 vote footprints over the workgroup and derive the LDS window.
@@ -307,25 +320,39 @@ __device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams 
         th0 = wp.motion[0];
         th1 = wp.motion[1];
     }
-    if (threadIdx.x == 0) {
-        s_box[0] = 0x7fffffff;  // min row
-        s_box[1] = -0x7fffffff; // max row
-        s_box[2] = 0x7fffffff;  // min col
-        s_box[3] = -0x7fffffff; // max col
-    }
     int mnr = 0x7fffffff, mxr = -0x7fffffff, mnc = 0x7fffffff, mxc = -0x7fffffff;
+    // 16-byte loads: lane l of iteration j reads events base + 2*(256 j + l) + {0, 1}; `base` is the
+    // segment start rounded down to an even index (the buffer is 16-byte aligned and padded), slot
+    // u = 2 j + e.  Consecutive lanes read consecutive 16 B: one coalesced 4 KiB request per wave.
+    const int64_t base = (int64_t)sg.x & ~(int64_t)1;
+    const int64_t seg_end = (int64_t)sg.x + sg.y;
+    uint4 raw[kEPT / 2];
 #pragma unroll
-    for (int j = 0; j < kEPT; ++j) {
-        const int i = (int)threadIdx.x + j * 256;
-        rc[j] = 0u;
-        if (i < sg.y) {
-            const Warped w = warp_one<MODEL, FRAC>(ev, (int64_t)sg.x + i, wp, tscale, th0, th1);
-            rc[j] = ((unsigned)(w.row + 16384) << 16) | (unsigned)(w.col + 16384);
-            fa[j] = w.a;
-            fb[j] = w.b;
+    for (int j = 0; j < kEPT / 2; ++j) {
+        const int64_t i0 = base + 2 * ((int64_t)j * 256 + threadIdx.x);
+        raw[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (i0 < seg_end) raw[j] = *reinterpret_cast<const uint4 *>(ev.ev + i0);
+    }
+#pragma unroll
+    for (int u = 0; u < kEPT; ++u) {
+        const int j = u >> 1;
+        const int64_t i = base + 2 * ((int64_t)j * 256 + threadIdx.x) + (u & 1);
+        const uint2 e = (u & 1) ? make_uint2(raw[j].z, raw[j].w) : make_uint2(raw[j].x, raw[j].y);
+        rc[u] = 0u;  // empty slot: finite defaults so masked arithmetic can never produce NaN
+        fa[u] = 0.f;
+        fb[u] = 0.f;
+        if (WANT_DT) {
+            fdt[u] = 0.f;
+            fsrc[u] = -1;
+        }
+        if (i >= sg.x && i < seg_end) {
+            const Warped w = warp_one<MODEL, FRAC>(ev, e, i, wp, tscale, th0, th1);
+            rc[u] = ((unsigned)(w.row + 16384) << 16) | (unsigned)(w.col + 16384);
+            fa[u] = w.a;
+            fb[u] = w.b;
             if (WANT_DT) {
-                fdt[j] = w.dt;
-                fsrc[j] = w.src;
+                fdt[u] = w.dt;
+                fsrc[u] = w.src;
             }
             mnr = min(mnr, w.row);
             mxr = max(mxr, w.row);
@@ -340,30 +367,38 @@ __device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams 
         mnc = min(mnc, __shfl_xor(mnc, o, kWave));
         mxc = max(mxc, __shfl_xor(mxc, o, kWave));
     }
-    __syncthreads();  // s_box initialised
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        atomicMin(&s_box[0], mnr);
-        atomicMax(&s_box[1], mxr);
-        atomicMin(&s_box[2], mnc);
-        atomicMax(&s_box[3], mxc);
+    if ((threadIdx.x & (kWave - 1)) == 0) {  // one slot of 4 ints per wave, combined by every thread after the barrier
+        const int wv = threadIdx.x / kWave;
+        s_box[4 * wv + 0] = mnr;
+        s_box[4 * wv + 1] = mxr;
+        s_box[4 * wv + 2] = mnc;
+        s_box[4 * wv + 3] = mxc;
     }
     __syncthreads();
+    const int bmnr = min(min(s_box[0], s_box[4]), min(s_box[8], s_box[12]));
+    const int bmxr = max(max(s_box[1], s_box[5]), max(s_box[9], s_box[13]));
+    const int bmnc = min(min(s_box[2], s_box[6]), min(s_box[10], s_box[14]));
+    const int bmxc = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
     Window win;
     // footprint rows [min, max + 1], clipped to the image
-    int r0 = max(s_box[0], 0), r1 = min(s_box[1] + 2, wp.Hp);
-    int c0 = max(s_box[2], 0), c1 = min(s_box[3] + 2, wp.Wp);
+    int r0 = max(bmnr, 0), r1 = min(bmxr + 2, wp.Hp);
+    int c0 = max(bmnc, 0), c1 = min(bmxc + 2, wp.Wp);
     int h = max(r1 - r0, 0), w = max(c1 - c0, 0);
-    if (h * w > kWinCap) {  // rare (very large displacements): keep the centre, the rest goes to global atomics
-        if (w > kWinMaxW) {
-            c0 += (w - kWinMaxW) / 2;
-            w = kWinMaxW;
-        }
-        const int hmax = kWinCap / w;
-        if (h > hmax) {
-            r0 += (h - hmax) / 2;
-            h = hmax;
-        }
+    win.clipped = false;
+    if (w > kWinMaxW) {  // rare (very large displacements): keep the centre, the rest goes to global memory
+        c0 += (w - kWinMaxW) / 2;
+        w = kWinMaxW;
+        win.clipped = true;
     }
+    int sh = 4;
+    while ((1 << sh) < w) ++sh;  // row stride 16 .. 128
+    const int hmax = kWinCap >> sh;
+    if (h > hmax) {
+        r0 += (h - hmax) / 2;
+        h = hmax;
+        win.clipped = true;
+    }
+    win.sh = sh;
     win.r0 = r0;
     win.c0 = c0;
     win.h = h;
@@ -376,122 +411,120 @@ __device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams 
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, bool FRAC>
 __global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg,
-                                              float *__restrict__ iwe) {
-    __shared__ int s_win[kWinCap];
-    __shared__ int s_box[4];
+                                              float *__restrict__ iwe, double *__restrict__ stat_zero) {
+    __shared__ int s_win[kWinCap + kWave];
+    __shared__ int s_box[16];
+    // the statistics accumulators of the image being filled are reset here (K2 follows in stream order)
+    if (stat_zero && blockIdx.x == 0 && threadIdx.x < 2 * 8) stat_zero[threadIdx.x] = 0.0;
     const int sidx = segment_of_block(nseg);
     if (sidx >= nseg) return;
+#if defined(CMAX_ABL) && CMAX_ABL == 3
+    return;
+#endif
     const int2 sg = segs[sidx];
+#if defined(CMAX_ABL) && CMAX_ABL == 4
+    if (sg.x == -12345) iwe[0] = 1.f;
+    return;
+#endif
+#if defined(CMAX_ABL) && CMAX_ABL == 5
+    {
+        const int64_t base = (int64_t)sg.x & ~(int64_t)1;
+        uint4 acc4 = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < kEPT / 2; ++j) {
+            const int64_t i0 = base + 2 * ((int64_t)j * 256 + threadIdx.x);
+            if (i0 < (int64_t)sg.x + sg.y) { uint4 v = *reinterpret_cast<const uint4 *>(ev.ev + i0); acc4.x ^= v.x; acc4.y ^= v.y; acc4.z ^= v.z; acc4.w ^= v.w; }
+        }
+        if ((acc4.x ^ acc4.y ^ acc4.z ^ acc4.w) == 0x12345u) iwe[0] = 1.f;
+        return;
+    }
+#endif
     unsigned rc[kEPT];
     float fa[kEPT], fb[kEPT], fdt[kEPT];
     int fsrc[kEPT];
     const Window win = phase_warp<MODEL, FRAC, false>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
-    const int wn = win.h * win.w;
+#if defined(CMAX_ABL) && CMAX_ABL == 1
+    if (win.h == -12345) iwe[0] = fa[0] + fb[1] + (float)rc[2];
+    return;
+#endif
+    const int wn = win.h << win.sh;
     for (int i = threadIdx.x; i < wn; i += 256) s_win[i] = 0;
     __syncthreads();
-    // phase B: 4 votes per event
+    // phase B: 4 votes per event, branch-free: a vote outside the window adds 0 to a per-lane scratch word
+    const int dummy = kDummy + (int)(threadIdx.x & (kWave - 1));
 #pragma unroll
-    for (int j = 0; j < kEPT; ++j) {
-        if (rc[j] == 0u) continue;
-        const int row = (int)(rc[j] >> 16) - 16384, col = (int)(rc[j] & 0xFFFFu) - 16384;
-        const float a = fa[j], b = fb[j], na = 1.f - a, nb = 1.f - b;
-        const float wv[4] = {na * nb, a * nb, na * b, a * b};  // w_pos0..3, event_image_converter.py:365-368
+    for (int u = 0; u < kEPT; ++u) {
+        const int row = (int)(rc[u] >> 16) - 16384, col = (int)(rc[u] & 0xFFFFu) - 16384;  // empty slot: (-16384, -16384)
+        const float a = fa[u], b = fb[u], na = 1.f - a, nb = 1.f - b;
+        const int lr = row - win.r0, lc = col - win.c0;
+        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
+        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
+        const int base = (lr << win.sh) + lc;
+        const int stride = 1 << win.sh;
+        // w_pos0..3, event_image_converter.py:365-368
+        atomicAdd(&s_win[(r_in0 && c_in0) ? base : dummy], (r_in0 && c_in0) ? __float2int_rn(na * nb * kFix) : 0);
+        atomicAdd(&s_win[(r_in1 && c_in0) ? base + stride : dummy], (r_in1 && c_in0) ? __float2int_rn(a * nb * kFix) : 0);
+        atomicAdd(&s_win[(r_in0 && c_in1) ? base + 1 : dummy], (r_in0 && c_in1) ? __float2int_rn(na * b * kFix) : 0);
+        atomicAdd(&s_win[(r_in1 && c_in1) ? base + stride + 1 : dummy], (r_in1 && c_in1) ? __float2int_rn(a * b * kFix) : 0);
+    }
+    if (win.clipped) {  // workgroup-uniform, rare: votes outside the LDS window but inside the image
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = row + (q & 1), c = col + (q >> 1);
-            const int lr = r - win.r0, lc = c - win.c0;
-            if ((unsigned)lr < (unsigned)win.h && (unsigned)lc < (unsigned)win.w) {
-                atomicAdd(&s_win[lr * win.w + lc], __float2int_rn(wv[q] * kFix));
-            } else if ((unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) {
-                atomic_add(&iwe[(int64_t)r * wp.Wp + c], wv[q]);  // outside the LDS window, inside the image
+        for (int u = 0; u < kEPT; ++u) {
+            if (rc[u] == 0u) continue;
+            const int row = (int)(rc[u] >> 16) - 16384, col = (int)(rc[u] & 0xFFFFu) - 16384;
+            const float a = fa[u], b = fb[u], na = 1.f - a, nb = 1.f - b;
+            const float wv[4] = {na * nb, a * nb, na * b, a * b};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = row + (q & 1), c = col + (q >> 1);
+                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
+                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) atomic_add(&iwe[(int64_t)r * wp.Wp + c], wv[q]);
             }
         }
     }
     __syncthreads();
-    // flush: one coalesced global atomic per touched window pixel
+#if defined(CMAX_ABL) && CMAX_ABL == 2
+    if (s_win[threadIdx.x] == -12345) iwe[0] = 1.f;
+    return;
+#endif
+    // flush: one coalesced global atomic per touched window pixel (a wave per window row)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (win.w >= 48) {
+    if (win.w > 32) {
         for (int r = wave; r < win.h; r += 4) {
             float *dst = iwe + (int64_t)(win.r0 + r) * wp.Wp + win.c0;
             for (int c = lane; c < win.w; c += kWave) {
-                const int v = s_win[r * win.w + c];
+                const int v = s_win[(r << win.sh) + c];
                 if (v != 0) atomic_add(&dst[c], (float)v * kInvFix);
             }
         }
-    } else {
-        for (int i = threadIdx.x; i < wn; i += 256) {
-            const int v = s_win[i];
-            if (v != 0) {
-                const int r = i / win.w, c = i - r * win.w;
-                atomic_add(&iwe[(int64_t)(win.r0 + r) * wp.Wp + win.c0 + c], (float)v * kInvFix);
+    } else {  // narrow window: two rows per wave
+        const int half = lane >> 5, c = lane & 31;
+        for (int r = 2 * wave + half; r < win.h; r += 8) {
+            if (c < win.w) {
+                const int v = s_win[(r << win.sh) + c];
+                if (v != 0) atomic_add(&iwe[(int64_t)(win.r0 + r) * wp.Wp + win.c0 + c], (float)v * kInvFix);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: contrast statistics of one image.  No atomics: workgroup b writes its partial sums
-//     part[2b] = sum x (variance) or sum gx^2+gy^2 (grad-mag), part[2b+1] = sum x^2; consumers add
-//     the <= kStatBlocksMax partials themselves (same-address fp64 atomics serialise at ~12 ns each).
+// K2: contrast statistics of one image (+ zeroing of the NEXT evaluation's vote image).
+//     Workgroup b adds its fp64 partials to sub-accumulator b % 8 of its slot:
+//     stat[slot][sub][0] = sum x (variance) or sum gx^2+gy^2 (grad-mag), [1] = sum x^2.
+//     Same-address fp64 atomics serialise at ~12 ns each (they cost 47 us in the first version), so
+//     they are spread over 8 addresses and consumers add the 8 values.  The accumulators are zeroed
+//     by workgroup 0 of the K1 launch that fills the image (stream order), so no memset node exists.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStatBlocksMax = 256;
 constexpr int kStatSlots = 5;  // reference times 0..3, slot 4 = un-warped image
-
-template <int COST>
-__global__ void __launch_bounds__(256) k_stats(const float *__restrict__ img, int H, int W, int omit, double *__restrict__ part) {
-    __shared__ double smem[2 * 4];
-    const int i0 = omit ? 1 : 0, h = H - 2 * i0, w = W - 2 * i0;
-    const int64_t n = (int64_t)h * w;
-    double v[2] = {0.0, 0.0};
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(q / w) + i0, j = (int)(q % w) + i0;
-        if (COST == CMAX_COST_VARIANCE) {
-            const double x = (double)img[(int64_t)i * W + j];
-            v[0] += x;
-            v[1] += x * x;
-        } else {
-            double gx, gy;
-            sobel8<float>(img, H, W, i, j, gx, gy);
-            v[0] += gx * gx + gy * gy;
-        }
-    }
-    block_sum<2>(v, smem);
-    if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = v[0];
-        part[2 * blockIdx.x + 1] = v[1];
-    }
-}
+constexpr int kStatSub = 8;    // sub-accumulators per slot
+constexpr int kStatStride = kStatSub * 2;
 
 struct ObjParams {
     int cost, normalized, minimize, negate, omit, n_ref;
     double mult[4];
-    int H, W;      // padded image
-    int nblk;      // workgroups of k_stats (partials per slot)
+    int H, W;  // padded image
 };
-
-// Sum the partials of every slot the objective uses into LDS: s_acc[2*slot + {0,1}].
-// Called by all threads of the workgroup (contains barriers).
-__device__ __forceinline__ void load_stats(const ObjParams &op, const double *__restrict__ part, double *s_acc) {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nw = blockDim.x / kWave;
-    for (int slot = wave; slot < kStatSlots; slot += nw) {
-        const bool used = slot < op.n_ref || (slot == 4 && op.normalized);
-        double a0 = 0.0, a1 = 0.0;
-        if (used) {
-            const double *p = part + (int64_t)slot * 2 * kStatBlocksMax;
-            for (int b = lane; b < op.nblk; b += kWave) {
-                a0 += p[2 * b];
-                a1 += p[2 * b + 1];
-            }
-        }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) {
-            s_acc[2 * slot] = a0;
-            s_acc[2 * slot + 1] = a1;
-        }
-    }
-    __syncthreads();
-}
 
 // raw contrast from the summed accumulators (variance: unbiased like torch.var, image_variance.py:55)
 __device__ __forceinline__ double contrast_value(int cost, const double *acc, double npix, double *mu_out) {
@@ -508,37 +541,116 @@ __device__ __forceinline__ double region_pixels(int H, int W, int omit) {
     return (double)(H - 2 * i0) * (double)(W - 2 * i0);
 }
 
-__device__ __forceinline__ double orig_value(const ObjParams &op, const double *s_acc) {
+// sum of the sub-accumulators of one slot
+__device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int slot, double (&acc)[2]) {
+    acc[0] = 0.0;
+    acc[1] = 0.0;
+#pragma unroll
+    for (int u = 0; u < kStatSub; ++u) {
+        acc[0] += stat[slot * kStatStride + 2 * u];
+        acc[1] += stat[slot * kStatStride + 2 * u + 1];
+    }
+}
+
+__device__ __forceinline__ double orig_value(const ObjParams &op, const double *stat) {
     // orig_iwe is NOT boundary-cropped for the variance (normalized_image_variance.py:40-41)
     const int omit_o = op.cost == CMAX_COST_VARIANCE ? 0 : op.omit;
-    return contrast_value(op.cost, s_acc + 8, region_pixels(op.H, op.W, omit_o), nullptr);
+    double acc[2];
+    stat_sum(stat, 4, acc);
+    return contrast_value(op.cost, acc, region_pixels(op.H, op.W, omit_o), nullptr);
 }
 
 // dL/dv_k: chain factor of reference time k, and the mean of its image (variance)
-__device__ __forceinline__ double chain_coef(const ObjParams &op, const double *s_acc, int k, double *mu_out) {
+__device__ __forceinline__ double chain_coef(const ObjParams &op, const double *stat, int k, double *mu_out) {
     const double npix = region_pixels(op.H, op.W, op.omit);
-    const double v = contrast_value(op.cost, s_acc + 2 * k, npix, mu_out);
+    double acc[2];
+    stat_sum(stat, k, acc);
+    const double v = contrast_value(op.cost, acc, npix, mu_out);
     double coef;
     if (!op.normalized) coef = op.mult[k] * (op.minimize ? -1.0 : 1.0);
     else {
-        const double v_orig = orig_value(op, s_acc);
+        const double v_orig = orig_value(op, stat);
         coef = op.mult[k] * (op.minimize ? -v_orig / (v * v) : 1.0 / v_orig);
     }
     return op.negate ? -coef : coef;
+}
+
+// loss and per-reference-time contrasts -> result[0..5]
+__device__ void write_result(const ObjParams &op, const double *stat, double *__restrict__ result) {
+    const double npix = region_pixels(op.H, op.W, op.omit);
+    const double v_orig = op.normalized ? orig_value(op, stat) : 0.0;
+    double loss = 0.0;
+    for (int k = 0; k < op.n_ref; ++k) {
+        double acc[2];
+        stat_sum(stat, k, acc);
+        const double v = contrast_value(op.cost, acc, npix, nullptr);
+        result[1 + k] = v;
+        if (!op.normalized) loss += op.mult[k] * (op.minimize ? -v : v);
+        else loss += op.mult[k] * (op.minimize ? v_orig / v : v / v_orig);
+    }
+    result[0] = op.negate ? -loss : loss;
+    result[5] = v_orig;
+}
+
+template <int COST>
+__global__ void __launch_bounds__(256)
+k_stats(const float *__restrict__ img, int H, int W, int omit, double *__restrict__ stat_slot, float *__restrict__ zero_img) {
+    __shared__ double smem[2 * 4];
+    const unsigned npix = (unsigned)H * (unsigned)W;
+    const int i0 = omit ? 1 : 0;
+    const unsigned stride = gridDim.x * 256u;
+    double v[2] = {0.0, 0.0};
+    for (unsigned base = blockIdx.x * 256u + threadIdx.x; base < npix; base += 4u * stride) {
+        float x[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // 4 independent loads in flight per thread
+            const unsigned p = base + (unsigned)u * stride;
+            const unsigned r = p / (unsigned)W, c = p - r * (unsigned)W;
+            in[u] = p < npix && (int)r >= i0 && (int)r < H - i0 && (int)c >= i0 && (int)c < W - i0;
+            x[u] = 0.f;
+            if (COST == CMAX_COST_VARIANCE) {
+                if (in[u]) x[u] = img[p];
+            }
+            if (zero_img && p < npix) zero_img[p] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (COST == CMAX_COST_VARIANCE) {
+                const double xd = (double)x[u];
+                v[0] += xd;
+                v[1] += xd * xd;
+            } else if (in[u]) {
+                const unsigned p = base + (unsigned)u * stride;
+                const int r = (int)(p / (unsigned)W), c = (int)(p - (unsigned)r * (unsigned)W);
+                double gx, gy;
+                sobel8<float>(img, H, W, r, c, gx, gy);
+                v[0] += gx * gx + gy * gy;
+            }
+        }
+    }
+    block_sum<2>(v, smem);
+    if (threadIdx.x == 0) {
+        double *a = stat_slot + 2 * (blockIdx.x % kStatSub);
+        atomic_add(&a[0], v[0]);
+        if (COST == CMAX_COST_VARIANCE) atomic_add(&a[1], v[1]);
+    }
+}
+
+__global__ void k_finalize(ObjParams op, const double *__restrict__ stat, double *__restrict__ result) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) write_result(op, stat, result);
 }
 
 // K2b: G[p] = dL/dv_k * dv_k/dI[p]   (needed when a blur transpose follows or for the grad-mag cost;
 //      the plain-variance gradient is folded into K3 instead)
 template <int COST>
 __global__ void __launch_bounds__(256)
-k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__restrict__ part, float *__restrict__ G) {
-    __shared__ double s_acc[2 * kStatSlots];
-    load_stats(op, part, s_acc);
+k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__restrict__ stat, float *__restrict__ G) {
     const int H = op.H, W = op.W;
     const int i0 = op.omit ? 1 : 0;
     const double npix = region_pixels(H, W, op.omit);
     double mu = 0.0;
-    const double coef = chain_coef(op, s_acc, k, &mu);
+    const double coef = chain_coef(op, stat, k, &mu);
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)H * W) return;
     const int i = (int)(p / W), j = (int)(p % W);
@@ -562,22 +674,14 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
 template <int MODEL, bool FRAC, bool FOLD>
 __global__ void __launch_bounds__(256)
 k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const float *__restrict__ img, ObjParams op, int k,
-       const double *__restrict__ part, double *__restrict__ gpart, float *__restrict__ gflow) {
-    __shared__ float s_win[kWinCap];
-    __shared__ int s_box[4];
-    __shared__ double s_acc[2 * kStatSlots];
+       const double *__restrict__ stat, double *__restrict__ gpart, float *__restrict__ gflow, double *__restrict__ result) {
+    __shared__ float s_win[kWinCap + kWave];
+    __shared__ int s_box[16];
     __shared__ double s_red[2 * 4];
     const int sidx = segment_of_block(nseg);
     if (sidx >= nseg) return;
     const int2 sg = segs[sidx];
     float c2 = 0.f, mu = 0.f;
-    if (FOLD) {
-        load_stats(op, part, s_acc);
-        double mud = 0.0;
-        const double coef = chain_coef(op, s_acc, k, &mud);
-        c2 = (float)(coef * 2.0 / (region_pixels(op.H, op.W, op.omit) - 1.0));
-        mu = (float)mud;
-    }
     const int i0 = op.omit ? 1 : 0;
     auto g_at = [&](int r, int c) -> float {  // dL/dIWE at an in-image pixel
         const float x = img[(int64_t)r * wp.Wp + c];
@@ -589,40 +693,66 @@ k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const 
     float fa[kEPT], fb[kEPT], fdt[kEPT];
     int fsrc[kEPT];
     const Window win = phase_warp<MODEL, FRAC, true>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
-    const int wn = win.h * win.w;
-    for (int i = threadIdx.x; i < wn; i += 256) {
-        const int r = i / win.w, c = i - r * win.w;
-        s_win[i] = g_at(win.r0 + r, win.c0 + c);
+    if (FOLD) {  // after the event loads were issued: the statistics loads overlap with them
+        double mud = 0.0;
+        const double coef = chain_coef(op, stat, k, &mud);
+        c2 = (float)(coef * 2.0 / (region_pixels(op.H, op.W, op.omit) - 1.0));
+        mu = (float)mud;
     }
-    __syncthreads();
-    const int hw = wp.H * wp.W;
+#if defined(CMAX_ABL) && CMAX_ABL == 1
+    if (win.h == -12345) gpart[0] = fa[0] + fb[1] + (float)rc[2] + fdt[3] + fsrc[4] + c2 + mu;
+    return;
+#endif
     const int lane = threadIdx.x & (kWave - 1);
-    double acc[2] = {0.0, 0.0};
+    if (win.w > 32) {  // a wave per window row: coalesced, no integer division
+        for (int r = threadIdx.x / kWave; r < win.h; r += 4)
+            for (int c = lane; c < win.w; c += kWave) s_win[(r << win.sh) + c] = g_at(win.r0 + r, win.c0 + c);
+    } else {  // narrow window: two rows per wave
+        const int half = lane >> 5, c = lane & 31;
+        for (int r = 2 * (threadIdx.x / kWave) + half; r < win.h; r += 8)
+            if (c < win.w) s_win[(r << win.sh) + c] = g_at(win.r0 + r, win.c0 + c);
+    }
+    if (threadIdx.x < kWave) s_win[kDummy + threadIdx.x] = 0.f;  // masked corners read 0 from here
+    __syncthreads();
+#if defined(CMAX_ABL) && CMAX_ABL == 2
+    if (s_win[threadIdx.x] == -12345.f) gpart[0] = fa[0] + fb[1] + (float)rc[2] + fdt[3] + fsrc[4];
+    return;
+#endif
+    const int hw = wp.H * wp.W;
+    const int dummy = kDummy + lane;
+    const int stride = 1 << win.sh;
+    float accx = 0.f, accy = 0.f;
 #pragma unroll
     for (int j = 0; j < kEPT; ++j) {
-        float gx = 0.f, gy = 0.f, dt = 0.f;
-        int key = -1 - lane;  // unique per lane: empty slots never merge
-        if (rc[j] != 0u) {
-            const int row = (int)(rc[j] >> 16) - 16384, col = (int)(rc[j] & 0xFFFFu) - 16384;
-            float g[4];
+        const int row = (int)(rc[j] >> 16) - 16384, col = (int)(rc[j] & 0xFFFFu) - 16384;  // empty slot: far outside
+        const int lr = row - win.r0, lc = col - win.c0;
+        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
+        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
+        const int base = (lr << win.sh) + lc;
+        // g[0] = G00 (row, col), g[1] = G10 (row+1, col), g[2] = G01 (row, col+1), g[3] = G11; a corner
+        // outside the window reads the zero scratch word (outside the image: masked vote, zero gradient)
+        float g[4];
+        g[0] = s_win[(r_in0 && c_in0) ? base : dummy];
+        g[1] = s_win[(r_in1 && c_in0) ? base + stride : dummy];
+        g[2] = s_win[(r_in0 && c_in1) ? base + 1 : dummy];
+        g[3] = s_win[(r_in1 && c_in1) ? base + stride + 1 : dummy];
+        if (win.clipped && rc[j] != 0u) {  // workgroup-uniform, rare: corners outside the window but inside the image
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = row + (q & 1), c = col + (q >> 1);
-                const int lr = r - win.r0, lc = c - win.c0;
-                if ((unsigned)lr < (unsigned)win.h && (unsigned)lc < (unsigned)win.w) g[q] = s_win[lr * win.w + lc];
-                else if ((unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) g[q] = g_at(r, c);
-                else g[q] = 0.f;  // corner outside the image: masked vote, zero gradient
+                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
+                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) g[q] = g_at(r, c);
             }
-            // g[0] = G00 (row, col), g[1] = G10 (row+1, col), g[2] = G01 (row, col+1), g[3] = G11
-            const float a = fa[j], b = fb[j];
-            gx = (1.f - b) * (g[1] - g[0]) + b * (g[3] - g[2]);
-            gy = (1.f - a) * (g[2] - g[0]) + a * (g[3] - g[1]);
-            dt = fdt[j];
-            key = fsrc[j];
         }
+        const bool valid = rc[j] != 0u;
+        const float a = fa[j], b = fb[j];
+        const float dt = valid ? fdt[j] : 0.f;
+        const float gx = (1.f - b) * (g[1] - g[0]) + b * (g[3] - g[2]);
+        const float gy = (1.f - a) * (g[2] - g[0]) + a * (g[3] - g[1]);
+        const int key = valid ? fsrc[j] : -1 - lane;  // unique per lane: empty slots never merge
         if (MODEL == CMAX_MODEL_2DOF) {
-            acc[0] += (double)(dt * gx);
-            acc[1] += (double)(dt * gy);
+            accx = fmaf(dt, gx, accx);  // <= kEPT terms in fp32, then fp64 across the workgroup
+            accy = fmaf(dt, gy, accy);
         } else {
             // segmented inclusive scan over the wave: lanes hold consecutive sorted events, a run =
             // adjacent lanes with the same key (voxel keys of one pixel interleave time bins, so the
@@ -649,46 +779,30 @@ k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const 
         }
     }
     if (MODEL == CMAX_MODEL_2DOF) {
+        double acc[2] = {(double)accx, (double)accy};
         block_sum<2>(acc, s_red);
         if (threadIdx.x == 0) {
             gpart[2 * sidx] = acc[0];
             gpart[2 * sidx + 1] = acc[1];
         }
     }
+    // loss: all statistics are complete (K2 ran); done last, by the workgroup of the last segment
+    if (result && sidx == nseg - 1 && threadIdx.x == 0) write_result(op, stat, result);
 }
 
-// Last kernel of an evaluation (one workgroup): loss and per-slot values from the statistics
-// partials; 2-DoF gradient = sum of the per-segment partials of every K3 launch.
+// 2-DoF only: gradient = sum of the per-segment partials of every K3 launch (one workgroup).
 __global__ void __launch_bounds__(256)
-k_finish(ObjParams op, const double *__restrict__ part, const double *__restrict__ gpart, int n_gpart,
-         double *__restrict__ result, double *__restrict__ gtheta) {
-    __shared__ double s_acc[2 * kStatSlots];
+k_finish(const double *__restrict__ gpart, int n_gpart, double *__restrict__ gtheta) {
     __shared__ double s_red[2 * 4];
-    load_stats(op, part, s_acc);
-    if (threadIdx.x == 0) {
-        const double npix = region_pixels(op.H, op.W, op.omit);
-        const double v_orig = op.normalized ? orig_value(op, s_acc) : 0.0;
-        double loss = 0.0;
-        for (int k = 0; k < op.n_ref; ++k) {
-            const double v = contrast_value(op.cost, s_acc + 2 * k, npix, nullptr);
-            result[1 + k] = v;
-            if (!op.normalized) loss += op.mult[k] * (op.minimize ? -v : v);
-            else loss += op.mult[k] * (op.minimize ? v_orig / v : v / v_orig);
-        }
-        result[0] = op.negate ? -loss : loss;
-        result[5] = v_orig;
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n_gpart; i += blockDim.x) {
+        acc[0] += gpart[2 * i];
+        acc[1] += gpart[2 * i + 1];
     }
-    if (gtheta) {
-        double acc[2] = {0.0, 0.0};
-        for (int i = threadIdx.x; i < n_gpart; i += blockDim.x) {
-            acc[0] += gpart[2 * i];
-            acc[1] += gpart[2 * i + 1];
-        }
-        block_sum<2>(acc, s_red);
-        if (threadIdx.x == 0) {
-            gtheta[0] = acc[0];
-            gtheta[1] = acc[1];
-        }
+    block_sum<2>(acc, s_red);
+    if (threadIdx.x == 0) {
+        gtheta[0] = acc[0];
+        gtheta[1] = acc[1];
     }
 }
 
@@ -710,20 +824,20 @@ static float ref_fraction(int ref_mode, double frac) {
 }
 
 template <int MODEL>
-static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, float *img, hipStream_t s) {
+static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, float *img, double *stat_zero, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfVote, s);
-    if (h->has_frac) hipLaunchKernelGGL((k_vote<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img);
-    else hipLaunchKernelGGL((k_vote<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img);
+    if (h->has_frac) hipLaunchKernelGGL((k_vote<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
+    else hipLaunchKernelGGL((k_vote<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
 }
 
 template <int MODEL>
 static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const float *img, bool fold,
-                        const ObjParams &op, int k, double *gpart, float *gflow, hipStream_t s) {
+                        const ObjParams &op, int k, double *gpart, float *gflow, double *result, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfGrad, s);
 #define CMAX_LAUNCH_GRAD(FRAC, FOLD) \
-    hipLaunchKernelGGL((k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_part, gpart, gflow)
+    hipLaunchKernelGGL((k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result)
     if (h->has_frac) {
         if (fold) CMAX_LAUNCH_GRAD(true, true);
         else CMAX_LAUNCH_GRAD(true, false);
@@ -736,8 +850,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 
 static EvView ev_view(const cmax_handle_s *h) {
     EvView ev;
-    ev.xyb = h->xyb;
-    ev.tau = h->tau;
+    ev.ev = h->evp;
     ev.rx = h->rx;
     ev.ry = h->ry;
     ev.n = h->n;
@@ -762,17 +875,21 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
 
 // raw votes of one reference time into `raw` (zeroed here)
 static int vote_image(cmax_handle_s *h, int model, const float *motion, int T, int ref_mode, double frac, int normalize,
-                      float *raw, hipStream_t s) {
+                      float *raw, bool already_zero, int stat_slot, hipStream_t s) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
-    CMAX_CHECK_HIP(hipMemsetAsync(raw, 0, npix * sizeof(float), s));
-    if (h->n == 0) return 0;
+    if (!already_zero) CMAX_CHECK_HIP(hipMemsetAsync(raw, 0, npix * sizeof(float), s));
+    double *stat_zero = stat_slot >= 0 ? h->d_stat + stat_slot * kStatStride : nullptr;
+    if (h->n == 0) {  // no K1 launch on this rank: reset the accumulators explicitly
+        if (stat_zero) CMAX_CHECK_HIP(hipMemsetAsync(stat_zero, 0, kStatStride * sizeof(double), s));
+        return 0;
+    }
     const EvView ev = ev_view(h);
     const WarpParams wp = warp_params(h, motion, T, ref_mode, frac, normalize);
     switch (model) {
-        case CMAX_MODEL_2DOF: launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, raw, s); break;
-        case CMAX_MODEL_DENSE: launch_vote<CMAX_MODEL_DENSE>(h, ev, wp, raw, s); break;
-        case CMAX_MODEL_VOXEL: launch_vote<CMAX_MODEL_VOXEL>(h, ev, wp, raw, s); break;
-        default: launch_vote<-1>(h, ev, wp, raw, s); break;
+        case CMAX_MODEL_2DOF: launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, raw, stat_zero, s); break;
+        case CMAX_MODEL_DENSE: launch_vote<CMAX_MODEL_DENSE>(h, ev, wp, raw, stat_zero, s); break;
+        case CMAX_MODEL_VOXEL: launch_vote<CMAX_MODEL_VOXEL>(h, ev, wp, raw, stat_zero, s); break;
+        default: launch_vote<-1>(h, ev, wp, raw, stat_zero, s); break;
     }
     CMAX_CHECK_LAUNCH();
     return 0;
@@ -793,19 +910,22 @@ static int blur_image(cmax_handle_s *h, double sigma, const float *raw, float *b
 }
 
 static int stat_blocks(const cmax_handle_s *h) {
-    // ~8 pixels per thread, between 32 and kStatBlocksMax workgroups
-    int64_t b = ((int64_t)h->Hp * h->Wp + 2047) / 2048;
-    if (b < 32) b = 32;
+    // ~4 pixels per thread, at most kStatBlocksMax workgroups
+    int64_t b = ((int64_t)h->Hp * h->Wp + 1023) / 1024;
+    if (b < 1) b = 1;
     if (b > kStatBlocksMax) b = kStatBlocksMax;
     return (int)b;
 }
 
-static int launch_stats(cmax_handle_s *h, int cost, const float *img, int Hp, int Wp, int omit, int slot, hipStream_t s) {
+// statistics of `img` -> stat[slot] (accumulators zeroed by the K1 launch); optionally zero `zero_img`
+static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, int slot, float *zero_img, hipStream_t s) {
     const int grid = stat_blocks(h);
-    double *part = h->d_part + (int64_t)slot * 2 * kStatBlocksMax;
+    double *stat_slot = h->d_stat + slot * kStatStride;
     ProfScope prof(h, kProfStats, s);
-    if (cost == CMAX_COST_VARIANCE) hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, Hp, Wp, omit, part);
-    else hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, Hp, Wp, omit, part);
+    if (cost == CMAX_COST_VARIANCE)
+        hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, stat_slot, zero_img);
+    else
+        hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, stat_slot, zero_img);
     CMAX_CHECK_LAUNCH();
     return 0;
 }
@@ -836,12 +956,12 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     h->ntc = div_up(W, kTile);
     h->nkeys = h->ntr * h->ntc * kTile * kTile;
     const int64_t npix = (int64_t)h->Hp * h->Wp;
-    int rc = dev_alloc(h, &h->imgs, 5 * npix);
+    int rc = dev_alloc(h, &h->imgs, 2 * 5 * npix);
     for (int k = 0; k < 5 && !rc; ++k) rc = dev_alloc(h, &h->iweb[k], npix);
     if (!rc) rc = dev_alloc(h, &h->G, npix);
     if (!rc) rc = dev_alloc(h, &h->Gt, npix);
     if (!rc) rc = dev_alloc(h, &h->d_tmm, 2);
-    if (!rc) rc = dev_alloc(h, &h->d_part, kStatSlots * kStatBlocksMax * 2);
+    if (!rc) rc = dev_alloc(h, &h->d_stat, kStatSlots * kStatStride);
     if (!rc) rc = dev_alloc(h, &h->counts, h->nkeys + 1);
     if (!rc) rc = dev_alloc(h, &h->cursor, h->nkeys);
     if (!rc) rc = dev_alloc(h, &h->d_flags, 2);
@@ -861,15 +981,14 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->G);
     dev_free(&h->Gt);
     dev_free(&h->d_tmm);
-    dev_free(&h->d_part);
+    dev_free(&h->d_stat);
     dev_free(&h->d_gpart);
     dev_free(&h->counts);
     dev_free(&h->cursor);
     dev_free(&h->d_flags);
     dev_free(&h->d_tile_start);
     dev_free(&h->d_segs);
-    dev_free(&h->xyb);
-    dev_free(&h->tau);
+    dev_free(&h->evp);
     dev_free(&h->rx);
     dev_free(&h->ry);
     dev_free(&h->tau64);
@@ -892,14 +1011,12 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     if (n > h->cap) {
         // the old buffers may still be in use by work queued on the stream
         CMAX_CHECK_HIP(hipStreamSynchronize(s));
-        dev_free(&h->xyb);
-        dev_free(&h->tau);
+        dev_free(&h->evp);
         dev_free(&h->rx);
         dev_free(&h->ry);
         dev_free(&h->tau64);
         dev_free(&h->key_tmp);
-        int rc = dev_alloc(h, &h->xyb, n);
-        if (!rc) rc = dev_alloc(h, &h->tau, n);
+        int rc = dev_alloc(h, &h->evp, n + 2);  // +2: the vector loads may touch one event past the end
         if (!rc) rc = dev_alloc(h, &h->rx, n);
         if (!rc) rc = dev_alloc(h, &h->ry, n);
         if (!rc) rc = dev_alloc(h, &h->tau64, n);
@@ -929,8 +1046,8 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     if (dtype == CMAX_F32) hipLaunchKernelGGL(k_pack_hist<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->H, h->W, h->ntc, h->key_tmp, h->counts, h->d_flags);
     else hipLaunchKernelGGL(k_pack_hist<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->H, h->W, h->ntc, h->key_tmp, h->counts, h->d_flags);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, h->counts, h->nkeys);
-    if (dtype == CMAX_F32) hipLaunchKernelGGL(k_scatter<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->xyb, h->tau, h->rx, h->ry, h->tau64);
-    else hipLaunchKernelGGL(k_scatter<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->xyb, h->tau, h->rx, h->ry, h->tau64);
+    if (dtype == CMAX_F32) hipLaunchKernelGGL(k_scatter<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
+    else hipLaunchKernelGGL(k_scatter<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
     CMAX_CHECK_LAUNCH();
     // once per batch: how many events survived, whether any source coordinate is fractional, and the
     // per-tile event ranges from which the segment work list is cut
@@ -992,7 +1109,7 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     if (n_time_bin == h->n_time_bin) return 0;
     h->n_time_bin = n_time_bin;
     if (h->n == 0) return 0;
-    hipLaunchKernelGGL(k_rebin, dim3(stream_grid(h->n, 256)), dim3(256), 0, (hipStream_t)stream, h->n, h->tau64, n_time_bin, h->xyb);
+    hipLaunchKernelGGL(k_rebin, dim3(stream_grid(h->n, 256)), dim3(256), 0, (hipStream_t)stream, h->n, h->tau64, n_time_bin, h->evp);
     CMAX_CHECK_LAUNCH();
     return 0;
 }
@@ -1004,8 +1121,8 @@ int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mod
     CMAX_REQUIRE(model <= CMAX_MODEL_VOXEL, "iwe: model");
     CMAX_REQUIRE(model != CMAX_MODEL_VOXEL || (T > 0 && T == h->n_time_bin), "iwe: voxel T must match the handle's time bins");
     hipStream_t s = (hipStream_t)stream;
-    float *raw = sigma > 0 ? h->imgs : iwe_out;
-    int rc = vote_image(h, model, motion, T, ref_mode, ref_frac, normalize_t, raw, s);
+    float *raw = sigma > 0 ? h->G : iwe_out;  // G is scratch outside cmax_objective
+    int rc = vote_image(h, model, motion, T, ref_mode, ref_frac, normalize_t, raw, false, -1, s);
     if (rc) return rc;
     const float *img = nullptr;
     return blur_image(h, sigma, raw, iwe_out, &img, s);
@@ -1025,34 +1142,39 @@ static bool orig_cache_hit(const cmax_handle_s *h, const cmax_objective_t *d) {
     return h->orig_valid && h->orig_sigma == d->sigma && h->orig_cost == d->cost && h->orig_omit == d->omit_boundary;
 }
 
+// votes of every reference time (+ the un-warped image when needed) into images[0 .. n_images);
+// zero_mask bit k: images[k] is already zero (the handle's double-buffered images)
+static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
+                          int *n_images_out, hipStream_t s) {
+    const int64_t npix = (int64_t)h->Hp * h->Wp;
+    for (int k = 0; k < d->n_ref; ++k) {
+        int rc = vote_image(h, d->model, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t, images + k * npix,
+                            (zero_mask >> k) & 1u, k, s);
+        if (rc) return rc;
+    }
+    int n_images = d->n_ref;
+    if (d->normalized && !orig_cache_hit(h, d)) {  // un-warped image, once per batch (patch_contrast_base.py:295-301)
+        int rc = vote_image(h, -1, nullptr, 0, CMAX_REF_FIRST, 0.0, 1, images + (int64_t)d->n_ref * npix,
+                            (zero_mask >> d->n_ref) & 1u, 4, s);
+        if (rc) return rc;
+        ++n_images;
+    }
+    *n_images_out = n_images;
+    return 0;
+}
+
 int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, int *n_images_host,
                         cmax_stream_t stream) {
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(images && n_images_host, "objective_vote: images / n_images_host");
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t npix = (int64_t)h->Hp * h->Wp;
-    for (int k = 0; k < d->n_ref; ++k) {
-        rc = vote_image(h, d->model, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t, images + k * npix, s);
-        if (rc) return rc;
-    }
-    int n_images = d->n_ref;
-    if (d->normalized && !orig_cache_hit(h, d)) {  // un-warped image, once per batch (patch_contrast_base.py:295-301)
-        rc = vote_image(h, -1, nullptr, 0, CMAX_REF_FIRST, 0.0, 1, images + (int64_t)d->n_ref * npix, s);
-        if (rc) return rc;
-        ++n_images;
-    }
-    *n_images_host = n_images;
-    return 0;
+    return objective_vote(h, d, motion, images, 0u, n_images_host, (hipStream_t)stream);
 }
 
-int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
-                          double *result, void *grad, cmax_stream_t stream) {
-    int rc = check_objective_args(h, d, motion);
-    if (rc) return rc;
-    CMAX_REQUIRE(images && result, "objective_finish: images / result");
-    CMAX_REQUIRE(n_images == d->n_ref || n_images == d->n_ref + 1, "objective_finish: n_images");
-    hipStream_t s = (hipStream_t)stream;
+// zero_next: base of the image buffer of the NEXT evaluation (k_stats of image k zeroes zero_next[k]) or nullptr
+static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
+                            float *zero_next, double *result, void *grad, hipStream_t s) {
+    int rc = 0;
     const int Hp = h->Hp, Wp = h->Wp;
     const int64_t npix = (int64_t)Hp * Wp;
     const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
@@ -1068,7 +1190,6 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const floa
     for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
     op.H = Hp;
     op.W = Wp;
-    op.nblk = stat_blocks(h);
 
     // statistics of the un-warped image (slot 4) are cached per batch
     if (d->normalized) {
@@ -1078,7 +1199,7 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const floa
             if (rc) return rc;
             // orig_iwe is NOT boundary-cropped for the variance (normalized_image_variance.py:40-41)
             const int omit_o = d->cost == CMAX_COST_VARIANCE ? 0 : d->omit_boundary;
-            rc = launch_stats(h, d->cost, img, Hp, Wp, omit_o, 4, s);
+            rc = launch_stats(h, d->cost, img, omit_o, 4, zero_next ? zero_next + (int64_t)d->n_ref * npix : nullptr, s);
             if (rc) return rc;
             h->orig_valid = true;
             h->orig_sigma = d->sigma;
@@ -1096,53 +1217,67 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const floa
         rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
         if (rc) return rc;
         h->last_iwe[k] = img;
-        rc = launch_stats(h, d->cost, img, Hp, Wp, d->omit_boundary, k, s);
+        rc = launch_stats(h, d->cost, img, d->omit_boundary, k, zero_next ? zero_next + k * npix : nullptr, s);
         if (rc) return rc;
     }
+    if (!grad || h->n == 0) {  // value only (or a rank without events): the loss needs its own tiny launch
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, op, h->d_stat, result);
+        CMAX_CHECK_LAUNCH();
+    }
+    if (!grad) return 0;
 
     const bool two_dof = d->model == CMAX_MODEL_2DOF;
-    int n_gpart = 0;
-    if (grad && h->n > 0) {
-        // backward: dL/dIWE (folded into K3 for the plain variance; otherwise G image + blur transpose)
-        // and the per-event gather, accumulated over the reference times
-        if (!two_dof) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
-        const EvView ev = ev_view(h);
-        const bool fold = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
-        double k0 = 0, k1 = 0;
-        if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
-        for (int k = 0; k < d->n_ref; ++k) {
-            const float *gsrc = h->last_iwe[k];
-            if (!fold) {
-                float *Gk = d->sigma > 0 ? h->Gt : h->G;
-                {
-                    ProfScope prof(h, kProfGimage, s);
-                    if (d->cost == CMAX_COST_VARIANCE)
-                        hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_part, Gk);
-                    else
-                        hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_part, Gk);
-                }
-                if (d->sigma > 0)
-                    hipLaunchKernelGGL(k_blur3_adj<float>, dim3(div_up(npix, 256)), dim3(256), 0, s, Gk, Hp, Wp, (float)k0, (float)k1, h->G);
-                CMAX_CHECK_LAUNCH();
-                gsrc = h->G;
-            }
-            const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t);
-            double *gpart = h->d_gpart + (int64_t)k * h->nseg * 2;
-            switch (d->model) {
-                case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, gsrc, fold, op, k, gpart, nullptr, s); break;
-                case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, s); break;
-                default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, s); break;
-            }
-            CMAX_CHECK_LAUNCH();
-        }
-        n_gpart = two_dof ? d->n_ref * h->nseg : 0;
-    } else if (grad) {
-        CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));  // this rank holds no events of the batch
+    if (h->n == 0) {  // this rank holds no events of the batch
+        CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+        return 0;
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, op, h->d_part, h->d_gpart, n_gpart, result,
-                       (grad && two_dof && h->n > 0) ? (double *)grad : nullptr);
-    CMAX_CHECK_LAUNCH();
+    // backward: dL/dIWE (folded into K3 for the plain variance; otherwise G image + blur transpose)
+    // and the per-event gather, accumulated over the reference times
+    if (!two_dof) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+    const EvView ev = ev_view(h);
+    const bool fold = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
+    double k0 = 0, k1 = 0;
+    if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
+    for (int k = 0; k < d->n_ref; ++k) {
+        const float *gsrc = h->last_iwe[k];
+        if (!fold) {
+            float *Gk = d->sigma > 0 ? h->Gt : h->G;
+            {
+                ProfScope prof(h, kProfGimage, s);
+                if (d->cost == CMAX_COST_VARIANCE)
+                    hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
+                else
+                    hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
+            }
+            if (d->sigma > 0)
+                hipLaunchKernelGGL(k_blur3_adj<float>, dim3(div_up(npix, 256)), dim3(256), 0, s, Gk, Hp, Wp, (float)k0, (float)k1, h->G);
+            CMAX_CHECK_LAUNCH();
+            gsrc = h->G;
+        }
+        const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t);
+        double *gpart = h->d_gpart + (int64_t)k * h->nseg * 2;
+        double *res = k == d->n_ref - 1 ? result : nullptr;  // the last K3 launch also writes the loss
+        switch (d->model) {
+            case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, gsrc, fold, op, k, gpart, nullptr, res, s); break;
+            case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, s); break;
+            default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, s); break;
+        }
+        CMAX_CHECK_LAUNCH();
+    }
+    if (two_dof) {
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)grad);
+        CMAX_CHECK_LAUNCH();
+    }
     return 0;
+}
+
+int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
+                          double *result, void *grad, cmax_stream_t stream) {
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(images && result, "objective_finish: images / result");
+    CMAX_REQUIRE(n_images == d->n_ref || n_images == d->n_ref + 1, "objective_finish: n_images");
+    return objective_finish(h, d, motion, images, n_images, nullptr, result, grad, (hipStream_t)stream);
 }
 
 int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad,
@@ -1159,10 +1294,20 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *moti
         if (grad) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
         return 0;
     }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t npix = (int64_t)h->Hp * h->Wp;
+    float *cur = h->imgs + (int64_t)h->cur_buf * 5 * npix;
+    float *nxt = h->imgs + (int64_t)(h->cur_buf ^ 1) * 5 * npix;
     int n_images = 0;
-    rc = cmax_objective_vote(h, d, motion, h->imgs, &n_images, stream);
+    rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s);
     if (rc) return rc;
-    return cmax_objective_finish(h, d, motion, h->imgs, n_images, result, grad, stream);
+    const unsigned used = (1u << n_images) - 1u;
+    h->zero_mask[h->cur_buf] &= ~used;  // now holds votes
+    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s);
+    if (rc) return rc;
+    h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
+    h->cur_buf ^= 1;
+    return 0;
 }
 
 int cmax_sizeof_objective(void) { return (int)sizeof(cmax_objective_t); }
