@@ -70,6 +70,7 @@ SIGNATURES = {
     "cmax_flow_step_adj": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_int, c_vp, c_vp, c_vp]),
     "cmax_voxel_construct": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cmax_voxel_construct_adj": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cmax_patch_to_dense": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cmax_create": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
     "cmax_destroy": (c_int, [c_vp]),
     "cmax_set_events": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_dbl, c_dbl, c_int, c_vp]),

@@ -302,3 +302,34 @@ def construct_dense_flow_voxel(flow, time_bin: int, scheme: str = "upwind", t0_l
     if scheme not in SCHEME_CODES:
         raise NotImplementedError(f"scheme {scheme!r}: only 'burgers' and 'upwind' are built (see DESIGN.md)")
     return _VoxelFn.apply(_cuda(flow, "flow"), int(time_bin), t0, SCHEME_CODES[scheme])
+
+
+# ------------------------------------------------------------------------------------------------
+class _PatchToDenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, motion, image_size, sliding_window, pad):
+        _, ph, pw = motion.shape
+        H, W = image_size
+        flow = torch.empty((2, H, W), dtype=motion.dtype, device=motion.device)
+        check(_lib.load().cmax_patch_to_dense(_ptr(motion), _code(motion), ph, pw, pad[0], pad[1], sliding_window[0],
+                                              sliding_window[1], H, W, 0, _ptr(flow), _stream()))
+        ctx.meta = (ph, pw, H, W, sliding_window, pad)
+        return flow
+
+    @staticmethod
+    def backward(ctx, gflow):
+        ph, pw, H, W, sliding_window, pad = ctx.meta
+        gflow = gflow.contiguous()
+        gm = torch.empty((2, ph, pw), dtype=gflow.dtype, device=gflow.device)
+        check(_lib.load().cmax_patch_to_dense(_ptr(gflow), _code(gflow), ph, pw, pad[0], pad[1], sliding_window[0],
+                                              sliding_window[1], H, W, 1, _ptr(gm), _stream()))
+        return gm, None, None, None
+
+
+def patch_to_dense(motion, image_size, sliding_window, pad):
+    """interpolate_dense_flow_from_patch_tensor for a [2,ph,pw] patch motion (bilinear filter)
+    (src/solver/patch_contrast_base.py:462-506)."""
+    _lib.require_gpu()
+    motion = _cuda(motion, "motion")
+    return _PatchToDenseFn.apply(motion, (int(image_size[0]), int(image_size[1])),
+                                 (int(sliding_window[0]), int(sliding_window[1])), (int(pad[0]), int(pad[1])))

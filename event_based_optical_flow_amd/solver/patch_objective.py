@@ -1,0 +1,57 @@
+"""The optimiser's objective for patch-based flow: x[2 * n_patch] -> loss, entirely on the GPU.
+
+Equivalent of `PyramidalPatchContrastMaximization.objective_scipy`
+(src/solver/patch_contrast_pyramid.py:430-462) + `motion_to_dense_flow` (464-516) for one scale:
+  patch motion -> dense flow (cmax_patch_to_dense, patch_contrast_base.py:462-506) -> x t_scale
+  [-> Burgers / upwind voxel (cmax_voxel_construct)] -> fused contrast objective (cmax_objective)
+  [+ weight * total_variation(patch motion)].
+Every stage is a HIP kernel with a hand-written adjoint; torch only chains them on the autograd tape.
+"""
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+
+from .. import functional as F
+from ..cmax import CMaxHandle, ContrastObjective
+
+
+def patch_pad(patch_size, sliding_window, patch_shift=(0, 0)) -> Tuple[int, int]:
+    """pad_h, pad_w of the reference's interpolation (patch_contrast_base.py:470-479)."""
+    return tuple(int(patch_size[k] / 2 // sliding_window[k]) + patch_shift[k] // sliding_window[k] + 1 for k in range(2))
+
+
+class PatchFlowObjective:
+    def __init__(self, handle: CMaxHandle, t_scale: float, patch_image_size, patch_size, sliding_window,
+                 patch_shift=(0, 0), cost: str = "hybrid", cost_with_weight: Optional[Dict[str, Union[float, str]]] = None,
+                 blur_sigma: float = 1.0, time_aware: bool = False, time_bin: int = 10,
+                 flow_interpolation: str = "burgers", t0_flow_location: str = "middle", filter_type: str = "bilinear"):
+        if filter_type != "bilinear":
+            raise NotImplementedError("only the bilinear patch filter (the shipped configs) is built")
+        self.handle = handle
+        self.t_scale = float(t_scale)
+        self.patch_image_size = (int(patch_image_size[0]), int(patch_image_size[1]))
+        self.sliding_window = (int(sliding_window[0]), int(sliding_window[1]))
+        self.pad = patch_pad(patch_size, sliding_window, patch_shift)
+        self.time_aware = bool(time_aware)
+        self.time_bin = int(time_bin)
+        self.flow_interpolation = flow_interpolation
+        self.t0_flow_location = t0_flow_location
+        if self.time_aware and handle.time_bin != self.time_bin:
+            handle.set_time_bins(self.time_bin)
+        model = "dense-flow-voxel" if self.time_aware else "dense-flow"
+        self.contrast = ContrastObjective(handle, model, cost=cost, cost_with_weight=cost_with_weight, sigma=blur_sigma)
+        self.device = handle.device  # read by scipy_autograd.TorchWrapper
+
+    def dense_flow(self, x: torch.Tensor) -> torch.Tensor:
+        """[2*ph*pw] patch motion -> [2,H,W] (or [T,2,H,W]) flow in pixel per NORMALISED time."""
+        motion = x.reshape((2,) + self.patch_image_size)
+        dense = F.patch_to_dense(motion, self.handle.image_size, self.sliding_window, self.pad) * self.t_scale
+        if self.time_aware:
+            # construct(dense_flow * t_scale / scale) * scale / t_scale with scale = 1, then * t_scale
+            # (patch_contrast_pyramid.py:452, 499-515): the voxel is built on the displacement field
+            dense = F.construct_dense_flow_voxel(dense, self.time_bin, self.flow_interpolation, self.t0_flow_location)
+        return dense
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.to(self.handle.device)
+        return self.contrast(self.dense_flow(x), x.reshape((2,) + self.patch_image_size))

@@ -146,6 +146,13 @@ int cmax_voxel_construct(const void *F, int dtype, int T, int t0, int H, int W, 
 int cmax_voxel_construct_adj(const void *V, int dtype, int T, int t0, int H, int W, int scheme,
                              void *gV, void *gF, cmax_stream_t stream);
 
+/* interpolate_dense_flow_from_patch_tensor (src/solver/patch_contrast_base.py:462-506): patch motion
+ * [2,ph,pw] -> dense flow [2,H,W] = centre-crop(bilinear x(sw_h,sw_w), align_corners=False, of the
+ * replicate-padded NEGATED grid).  adjoint != 0: `motion` is dL/dflow [2,H,W], out = dL/dmotion
+ * [2,ph,pw] (overwritten).                                                                     */
+int cmax_patch_to_dense(const void *motion, int dtype, int ph, int pw, int pad_h, int pad_w, int sw_h,
+                        int sw_w, int H, int W, int adjoint, void *out, cmax_stream_t stream);
+
 /* =============================================================================================
  * Fused objective (the hot path): events are packed + sorted once per batch, then every
  * evaluation runs  warp+vote -> contrast -> gather-gradient  without materialising warped events.

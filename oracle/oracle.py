@@ -452,3 +452,56 @@ def objective(events, motion, motion_model, image_size, cost="image_variance", s
         total = np.zeros_like(np.asarray(motion, dtype=np.float64))
     out["grad"] = total
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# next-row 1: patch grid -> dense flow (src/solver/patch_contrast_base.py:462-506)
+# --------------------------------------------------------------------------------------------
+def patch_pad(patch_size, sliding_window, patch_shift=(0, 0)):
+    """pad_h, pad_w of interpolate_dense_flow_from_patch_tensor (lines 470-479)."""
+    return tuple(int(patch_size[k] / 2 // sliding_window[k]) + patch_shift[k] // sliding_window[k] + 1 for k in range(2))
+
+
+def patch_to_dense(motion, image_size, sliding_window, pad):
+    m = _f64(motion)
+    _, ph, pw = m.shape
+    H, W = int(image_size[0]), int(image_size[1])
+    flow = np.empty((2, H, W))
+    lib().orc_patch_to_dense(_p(m), ph, pw, int(pad[0]), int(pad[1]), int(sliding_window[0]), int(sliding_window[1]), H, W, _p(flow))
+    return flow
+
+
+def patch_to_dense_adj(gflow, patch_image_size, sliding_window, pad):
+    g = _f64(gflow)
+    _, H, W = g.shape
+    ph, pw = int(patch_image_size[0]), int(patch_image_size[1])
+    gm = np.empty((2, ph, pw))
+    lib().orc_patch_to_dense_adj(_p(g), ph, pw, int(pad[0]), int(pad[1]), int(sliding_window[0]), int(sliding_window[1]), H, W, _p(gm))
+    return gm
+
+
+def solver_objective(events, x, image_size, patch_image_size, patch_size, sliding_window, patch_shift,
+                     cost="hybrid", cost_with_weight=None, sigma=1, time_aware=False, time_bin=10,
+                     flow_interpolation="burgers", t0_flow_location="middle"):
+    """PyramidalPatchContrastMaximization.objective_scipy (src/solver/patch_contrast_pyramid.py:430-462,
+    464-516) for one scale: x[2*ph*pw] (pixel / time unit) -> (loss, dloss/dx)."""
+    ev = _ev4(events)
+    ph, pw = int(patch_image_size[0]), int(patch_image_size[1])
+    t_scale = ev[:, 2].max() - ev[:, 2].min()  # line 444
+    pad = patch_pad(patch_size, sliding_window, patch_shift)
+    motion = np.asarray(x, dtype=np.float64).reshape(2, ph, pw)
+    dense = patch_to_dense(motion, image_size, sliding_window, pad)  # pixel / time unit
+    if time_aware:
+        # construct(dense * t_scale / scale) * scale / t_scale, scale = 1 (lines 499-515); then * t_scale (452)
+        voxel = construct_dense_flow_voxel(dense * t_scale, time_bin, flow_interpolation, t0_flow_location)
+        res = objective(ev, voxel, "dense-flow-voxel", image_size, cost=cost, sigma=sigma,
+                        cost_with_weight=cost_with_weight, coarse_flow=motion)
+        g_dense = construct_dense_flow_voxel_adj(voxel, res["grad"], flow_interpolation, t0_flow_location) * t_scale
+    else:
+        res = objective(ev, dense * t_scale, "dense-flow", image_size, cost=cost, sigma=sigma,
+                        cost_with_weight=cost_with_weight, coarse_flow=motion)
+        g_dense = res["grad"] * t_scale
+    g = patch_to_dense_adj(g_dense, (ph, pw), sliding_window, pad)
+    if res["grad_flow"] is not None:
+        g = g + res["grad_flow"]
+    return res["loss"], g.reshape(-1)

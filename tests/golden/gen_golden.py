@@ -318,7 +318,7 @@ def gen_hvp(rng):
          image_size=np.array([H, W]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--solver-only" not in sys.argv:
     torch.manual_seed(SEED)
     np.random.seed(SEED)
     rng = np.random.default_rng(SEED)
@@ -329,3 +329,56 @@ if __name__ == "__main__":
     gen_flow_voxel(rng)
     gen_objectives(rng)
     gen_hvp(rng)
+    gen_solver_objective(np.random.default_rng(SEED + 1))
+
+
+def gen_solver_objective(rng):
+    """Whole solver objective (the optimiser's `fun`): PyramidalPatchContrastMaximization.objective_scipy
+    (src/solver/patch_contrast_pyramid.py:430-462) = patch -> dense interpolation (+ Burgers voxel) ->
+    get_arg_for_cost -> hybrid cost, with the shipped YAML parameters on a reduced image."""
+    from src import solver as ref_solver
+
+    H, W = 68, 90
+    out = {"image_size": np.array([H, W])}
+    ev = make_events(5000, H, W, rng)
+    out["events"] = ev
+    for tag, time_aware in (("plain", False), ("burgers", True)):
+        slv_cfg = {
+            "method": "pyramidal_patch_contrast_maximization", "time_aware": time_aware,
+            "patch": {"initialize": "random", "scale": 4, "crop_height": 64, "crop_width": 80, "filter_type": "bilinear"},
+            "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
+            "cost": "hybrid", "outer_padding": 0,
+            "cost_with_weight": {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+            "iwe": {"method": "bilinear_vote", "blur_sigma": 1},
+        }
+        if time_aware:
+            slv_cfg.update({"time_bin": 10, "flow_interpolation": "burgers", "t0_flow_location": "middle"})
+        opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
+                   "parameters": {"trans_x": {"min": -150, "max": 150}, "trans_y": {"min": -150, "max": 150}}}
+        slv = ref_solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
+        slv._device = "cpu"
+        te = torch.from_numpy(ev)
+        for scale in (1, 3):
+            slv.overload_patch_configuration(scale)
+            ph, pw = slv.patch_image_size
+            x = rng.uniform(-300, 300, 2 * ph * pw)  # pixel / second: t_scale = 0.05 s -> +-15 px over the batch
+            tx = torch.from_numpy(x).requires_grad_()
+            loss = slv.objective_scipy(tx, te, {}, suppress_log=True)
+            (g,) = torch.autograd.grad(loss, tx)
+            dense = slv.interpolate_dense_flow_from_patch_tensor(torch.from_numpy(x))
+            k = f"{tag}_s{scale}"
+            out[k + "__x"] = x
+            out[k + "__loss"] = np.array(loss.item())
+            out[k + "__grad"] = g.numpy()
+            out[k + "__dense"] = dense.numpy()
+            out[k + "__patch_image_size"] = np.array([ph, pw])
+            out[k + "__patch_size"] = np.array(slv.patch_size)
+            out[k + "__sliding_window"] = np.array(slv.sliding_window)
+        out[tag + "__patch_shift"] = np.array(slv.patch_shift)
+    # vhp of the plain objective at the coarsest scale (Newton-CG's hessp)
+    slv.overload_patch_configuration(1)
+    save("solver_objective", **out)
+
+
+if __name__ == "__main__" and "--solver-only" in sys.argv:
+    gen_solver_objective(np.random.default_rng(SEED + 1))

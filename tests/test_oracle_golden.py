@@ -169,3 +169,25 @@ def test_objective_fractional_and_padding(golden, pad):
     np.testing.assert_allclose(res["loss"], g[f"frac_pad{pad}__loss"], rtol=1e-10)
     np.testing.assert_allclose(res["grad"], g[f"frac_pad{pad}__grad"], rtol=1e-8)
     np.testing.assert_allclose(res["iwes"]["iwe"], g[f"frac_pad{pad}__iwe"], rtol=1e-11, atol=1e-12)
+
+
+YAML_HYBRID_SOLVER = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01}
+
+
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
+@pytest.mark.parametrize("scale", [1, 3])
+def test_solver_objective(golden, tag, scale):
+    """patch -> dense interpolation (+ Burgers voxel) + YAML hybrid cost, against the reference solver's
+    objective_scipy value and autograd gradient."""
+    g = golden("solver_objective")
+    k = f"{tag}_s{scale}"
+    size = tuple(int(v) for v in g["image_size"])
+    pis, ps, sw, shift = g[k + "__patch_image_size"], g[k + "__patch_size"], g[k + "__sliding_window"], g[tag + "__patch_shift"]
+    pad = orc.patch_pad(ps, sw, shift)
+    dense = orc.patch_to_dense(g[k + "__x"].reshape(2, *pis), size, sw, pad)
+    np.testing.assert_allclose(dense, g[k + "__dense"], rtol=1e-12, atol=1e-12)
+    loss, grad = orc.solver_objective(g["events"], g[k + "__x"], size, pis, ps, sw, shift, cost="hybrid",
+                                      cost_with_weight=YAML_HYBRID_SOLVER, sigma=1, time_aware=(tag == "burgers"))
+    np.testing.assert_allclose(loss, g[k + "__loss"], rtol=1e-10)
+    ref = g[k + "__grad"]
+    np.testing.assert_allclose(grad, ref, rtol=1e-7, atol=1e-10 * np.abs(ref).max())
