@@ -54,6 +54,19 @@ def algorithmic_bytes(kernel: str, n: int, H: int, W: int, model: str, T: int) -
     return 4.0 * H * W
 
 
+def measured_traffic(workload: str, kernel: str):
+    """HBM bytes per launch from the PMC counters (profiles/r*_pmc_<workload>.json, collected with
+    tools/prof_pmc.sh and corrected as MI355X_MICROARCH.md prescribes); None if not collected."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)), reverse=True):
+        try:
+            return json.load(open(path))["traffic_bytes_per_launch"][workload][kernel]
+        except (KeyError, ValueError, OSError):
+            continue
+    return None
+
+
 def make_inputs(cfg, rank, world, seed=46):
     import event_based_optical_flow_amd as E
 
@@ -205,7 +218,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {"vote": "k_vote (K1 warp + bilinear vote)", "grad": "k_grad (K3 gather + gradient)",
                                                     "stats": "k_stats (K2)", "gimage": "k_gimage (K2b)"}[dominant],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": ab,
+                         "traffic": measured_traffic(args.workload, dominant), "algorithmic_bytes_per_launch": ab,
                          "launch_us": per_kernel[dominant],
                          "method": "HIP events on the launch stream, instrumented pass of the same K steps",
                          "all_kernels_us": per_kernel,

@@ -37,6 +37,7 @@ constexpr int kSegMax = 256 * kEPT - 8;       // events per segment (+1 for the 
                                               // |sum of votes| <= 2040 * 2^20 < 2^31
 constexpr int kWinCap = CMAX_WINCAP;          // LDS window capacity in 32-bit words (32 KiB)
 static_assert(kSegMax <= 2040, "fixed-point vote accumulation would overflow");
+constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (dense / voxel K3)
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
 constexpr float kFix = 1048576.f;             // 2^20: votes are accumulated as signed 12.20 fixed point
 constexpr float kInvFix = 1.f / 1048576.f;
@@ -51,6 +52,7 @@ struct EvView {
 struct WarpParams {
     int H, W, Hp, Wp, ph, pw;  // un-padded sensor, padded image, padding
     int T;                     // voxel bins
+    int ntc;                   // source tiles per tile row
     float d;                   // reference time as a fraction of the batch period
     int normalize;             // normalize_t
     const double *tmm;         // device (tmin, tmax)
@@ -76,7 +78,7 @@ struct cmax_handle_s {
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events
     int *d_tile_start = nullptr;  // [ntiles + 1] first sorted event of every source tile
-    int2 *d_segs = nullptr;       // [nseg] (begin, count) work items of the event kernels
+    int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int nseg = 0, seg_cap = 0;
     // images
     float *imgs = nullptr;                                  // [2 buffers][5, Hp, Wp] raw votes: one per reference time + un-warped
@@ -311,7 +313,7 @@ constexpr int kDummy = kWinCap;  // 64 scratch words behind the window: target o
 // bounding box of their 2x2 vote footprints over the workgroup and derive the LDS window.
 // rc[j] packs (row + 16384) << 16 | (col + 16384); 0 marks an empty slot.
 template <int MODEL, bool FRAC, bool WANT_DT>
-__device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams &wp, int2 sg, unsigned (&rc)[kEPT],
+__device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams &wp, int4 sg, unsigned (&rc)[kEPT],
                                               float (&fa)[kEPT], float (&fb)[kEPT], float (&fdt)[kEPT], int (&fsrc)[kEPT],
                                               int *s_box) {
     const float tscale = time_scale(wp);
@@ -352,7 +354,8 @@ __device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams 
             fb[u] = w.b;
             if (WANT_DT) {
                 fdt[u] = w.dt;
-                fsrc[u] = w.src;
+                // run key of the flow-gradient reduction: packed (row, col[, bin]) -- unique per cell, decoded by shifts
+                fsrc[u] = (int)(MODEL == CMAX_MODEL_VOXEL ? e.x : (e.x & 0x00FFFFFFu));
             }
             mnr = min(mnr, w.row);
             mxr = max(mxr, w.row);
@@ -410,7 +413,7 @@ __device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams 
 // K1: warp + bilinear vote.  LDS window in signed 12.20 fixed point (ds_add_u32), coalesced flush.
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, bool FRAC>
-__global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg,
+__global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const int4 *__restrict__ segs, int nseg,
                                               float *__restrict__ iwe, double *__restrict__ stat_zero) {
     __shared__ int s_win[kWinCap + kWave];
     __shared__ int s_box[16];
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const in
 #if defined(CMAX_ABL) && CMAX_ABL == 3
     return;
 #endif
-    const int2 sg = segs[sidx];
+    const int4 sg = segs[sidx];
 #if defined(CMAX_ABL) && CMAX_ABL == 4
     if (sg.x == -12345) iwe[0] = 1.f;
     return;
@@ -673,14 +676,21 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, bool FRAC, bool FOLD>
 __global__ void __launch_bounds__(256)
-k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const float *__restrict__ img, ObjParams op, int k,
+k_grad(EvView ev, WarpParams wp, const int4 *__restrict__ segs, int nseg, const float *__restrict__ img, ObjParams op, int k,
        const double *__restrict__ stat, double *__restrict__ gpart, float *__restrict__ gflow, double *__restrict__ result) {
     __shared__ float s_win[kWinCap + kWave];
     __shared__ int s_box[16];
     __shared__ double s_red[2 * 4];
+    // flow-gradient accumulators (x | y): voxel only -- measured on MI355X the dense model is faster with one
+    // global atomic per run (its runs are long and LDS occupancy matters more), the voxel model with LDS
+    constexpr bool kLdsAcc = MODEL == CMAX_MODEL_VOXEL;
+    __shared__ float s_acc[kLdsAcc ? 2 * kAccCells : 1];
     const int sidx = segment_of_block(nseg);
     if (sidx >= nseg) return;
-    const int2 sg = segs[sidx];
+    const int4 sg = segs[sidx];
+    if (kLdsAcc) {
+        for (int i = threadIdx.x; i < 2 * kAccCells; i += 256) s_acc[i] = 0.f;  // made visible by the barriers of phase_warp
+    }
     float c2 = 0.f, mu = 0.f;
     const int i0 = op.omit ? 1 : 0;
     auto g_at = [&](int r, int c) -> float {  // dL/dIWE at an in-image pixel
@@ -749,7 +759,7 @@ k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const 
         const float dt = valid ? fdt[j] : 0.f;
         const float gx = (1.f - b) * (g[1] - g[0]) + b * (g[3] - g[2]);
         const float gy = (1.f - a) * (g[2] - g[0]) + a * (g[3] - g[1]);
-        const int key = valid ? fsrc[j] : -1 - lane;  // unique per lane: empty slots never merge
+        const unsigned key = valid ? (unsigned)fsrc[j] : 0xFF000000u + (unsigned)lane * 0x1001u;  // invalid: (row, col) = (lane, lane), bin 255 -- never equal to a neighbour
         if (MODEL == CMAX_MODEL_2DOF) {
             accx = fmaf(dt, gx, accx);  // <= kEPT terms in fp32, then fp64 across the workgroup
             accy = fmaf(dt, gy, accy);
@@ -758,8 +768,8 @@ k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const 
             // adjacent lanes with the same key (voxel keys of one pixel interleave time bins, so the
             // scan carries head flags instead of comparing keys at a distance)
             float vx = -dt * gx, vy = -dt * gy;
-            const int kprev = __shfl_up(key, 1, kWave);
-            int head = (lane == 0 || kprev != key) ? 1 : 0;
+            const unsigned kprev = __shfl_up(key, 1, kWave);
+            int head = (lane == 0 || kprev != key || !valid) ? 1 : 0;
             const int hnext = __shfl_down(head, 1, kWave);  // evaluated by all lanes (no short-circuit around a shuffle)
             const int tail = (lane == kWave - 1) || (hnext != 0);
 #pragma unroll
@@ -772,10 +782,36 @@ k_grad(EvView ev, WarpParams wp, const int2 *__restrict__ segs, int nseg, const 
                     head |= h2;
                 }
             }
-            if (key >= 0 && tail) {  // last lane of its run holds the run's sum
-                atomic_add(&gflow[key], vx);
-                atomic_add(&gflow[key + hw], vy);
+            if (valid && tail) {  // last lane of its run holds the run's sum
+                // cell of the run in the workgroup's accumulator: [bin][tile - tile0][pixel in tile]
+                const int ix = (int)(key & 0xFFFu), iy = (int)((key >> 12) & 0xFFFu), bin = (int)(key >> 24);
+                const int tl = ((ix >> 4) * wp.ntc + (iy >> 4)) - sg.z;
+                const int cell = ((bin * sg.w + tl) << 8) + ((ix & 15) << 4) + (iy & 15);
+                if (kLdsAcc && (unsigned)cell < (unsigned)kAccCells) {
+                    atomic_add(&s_acc[cell], vx);  // ds_add_f32: slow per op, but only one per run
+                    atomic_add(&s_acc[kAccCells + cell], vy);
+                } else {  // accumulator too small for this segment (very many time bins): straight to memory
+                    const int64_t g = (int64_t)bin * 2 * hw + (int64_t)ix * wp.W + iy;
+                    atomic_add(&gflow[g], vx);
+                    atomic_add(&gflow[g + hw], vy);
+                }
             }
+        }
+    }
+    if (kLdsAcc) {
+        // flush: 64 lanes = 4 rows x 16 pixels of one source tile -> one global atomic per non-zero cell
+        __syncthreads();
+        const int nbin = MODEL == CMAX_MODEL_VOXEL ? wp.T : 1;
+        int ncell = (nbin * sg.w) << 8;
+        if (ncell > kAccCells) ncell = kAccCells;
+        for (int cell = threadIdx.x; cell < ncell; cell += 256) {
+            const float vx = s_acc[cell], vy = s_acc[kAccCells + cell];
+            if (vx == 0.f && vy == 0.f) continue;
+            const int bt = cell >> 8, bin = bt / sg.w, tile = sg.z + (bt - bin * sg.w);
+            const int ix = ((tile / wp.ntc) << 4) + ((cell >> 4) & 15), iy = ((tile % wp.ntc) << 4) + (cell & 15);
+            const int64_t g = (int64_t)bin * 2 * hw + (int64_t)ix * wp.W + iy;
+            atomic_add(&gflow[g], vx);
+            atomic_add(&gflow[g + hw], vy);
         }
     }
     if (MODEL == CMAX_MODEL_2DOF) {
@@ -866,6 +902,7 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
     wp.ph = h->ph;
     wp.pw = h->pw;
     wp.T = T;
+    wp.ntc = h->ntc;
     wp.d = ref_fraction(ref_mode, frac);
     wp.normalize = normalize;
     wp.tmm = h->d_tmm;
@@ -1063,22 +1100,29 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     h->n = n - flags[1];
     // Segments: consecutive tiles of one tile row are merged while they fit (sparse batches), a dense
     // tile is split into several segments; never more than kSegMax events (fixed-point range).
-    std::vector<int2> segs;
-    int begin = 0, count = 0, row_of_begin = -1;
+    // max tiles per segment: the flow-gradient accumulator of the dense / voxel K3 holds
+    // kAccCells cells = tiles * 256 pixels * time bins
+    const int bins = n_time_bin > 0 ? n_time_bin : 1;
+    int max_tiles = kAccCells / (256 * bins);
+    if (max_tiles < 1) max_tiles = 1;
+    std::vector<int4> segs;
+    int begin = 0, count = 0, row_of_begin = -1, tile0 = 0, tile_last = 0;
     auto close = [&]() {
-        if (count > 0) segs.push_back(make_int2(begin, count));
+        if (count > 0) segs.push_back(make_int4(begin, count, tile0, tile_last - tile0 + 1));
         count = 0;
     };
     for (int t = 0; t < ntiles; ++t) {
         int b = tile_start[t], c = tile_start[t + 1] - tile_start[t];
         const int trow = t / h->ntc;
         if (c == 0) continue;
-        if (count > 0 && (trow != row_of_begin || count + c > kSegMax)) close();
+        if (count > 0 && (trow != row_of_begin || count + c > kSegMax || t - tile0 + 1 > max_tiles)) close();
         while (c > 0) {
             if (count == 0) {
                 begin = b;
                 row_of_begin = trow;
+                tile0 = t;
             }
+            tile_last = t;
             const int take = c < kSegMax - count ? c : kSegMax - count;
             count += take;
             b += take;
@@ -1097,7 +1141,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         h->seg_cap = h->nseg;
     }
     if (h->nseg > 0) {
-        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, segs.data(), segs.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice, s));
         CMAX_CHECK_HIP(hipStreamSynchronize(s));  // `segs` is a host temporary
     }
     return 0;
