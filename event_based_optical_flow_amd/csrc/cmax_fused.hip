@@ -307,7 +307,53 @@ struct Window {
     int sh;            // LDS row stride = 1 << sh (power of two: a shift instead of an integer multiply per vote)
     bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
 };
-constexpr int kDummy = kWinCap;  // 64 scratch words behind the window: target of masked lanes (branch-free phase B)
+constexpr int kDummy = kWinCap;
+
+// ---- wave64 segmented inclusive scan without LDS traffic -------------------------------------------
+// ds_bpermute-based __shfl_up costs ~16 cycles per wave instruction on gfx950 and the 6-step scan of
+// (x, y, flag) was 60 % of the dense K3 (profiles/r01_ablation.txt).  DPP row shifts run on the VALU:
+// 4 steps inside each 16-lane row, then three v_readlane carries across the rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {  // lanes whose source is outside the row / wave read 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+
+// head: 1 on the first lane of every run.  On return (vx, vy) of the LAST lane of a run hold the run's sums.
+__device__ __forceinline__ void seg_scan64(int head, float &vx, float &vy, int lane) {
+    int f = head;  // "a run starts between my row's first lane and me"
+#define CMAX_SEG_STEP(CTRL)                                   \
+    {                                                         \
+        const float x2 = dpp_f<CTRL>(vx), y2 = dpp_f<CTRL>(vy); \
+        const int f2 = dpp_i<CTRL>(0, f);                     \
+        if (!f) {                                             \
+            vx += x2;                                         \
+            vy += y2;                                         \
+            f |= f2;                                          \
+        }                                                     \
+    }
+    CMAX_SEG_STEP(kDppRowShr1)
+    CMAX_SEG_STEP(kDppRowShr2)
+    CMAX_SEG_STEP(kDppRowShr4)
+    CMAX_SEG_STEP(kDppRowShr8)
+#undef CMAX_SEG_STEP
+    // carry the run that crosses a row boundary: lanes of row r without a head before them continue
+    // the run ending at the last lane of row r-1 (whose value already contains earlier carries)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), 16 * r - 1));
+        const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), 16 * r - 1));
+        if ((lane >> 4) == r && !f) {
+            vx += cx;
+            vy += cy;
+        }
+    }
+}  // 64 scratch words behind the window: target of masked lanes (branch-free phase B)
 
 // Phase A of both event kernels: warp this thread's <= kEPT events (kept in registers), reduce the
 // bounding box of their 2x2 vote footprints over the workgroup and derive the LDS window.
@@ -768,20 +814,11 @@ k_grad(EvView ev, WarpParams wp, const int4 *__restrict__ segs, int nseg, const 
             // adjacent lanes with the same key (voxel keys of one pixel interleave time bins, so the
             // scan carries head flags instead of comparing keys at a distance)
             float vx = -dt * gx, vy = -dt * gy;
-            const unsigned kprev = __shfl_up(key, 1, kWave);
-            int head = (lane == 0 || kprev != key || !valid) ? 1 : 0;
-            const int hnext = __shfl_down(head, 1, kWave);  // evaluated by all lanes (no short-circuit around a shuffle)
-            const int tail = (lane == kWave - 1) || (hnext != 0);
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const int h2 = __shfl_up(head, o, kWave);
-                const float x2 = __shfl_up(vx, o, kWave), y2 = __shfl_up(vy, o, kWave);
-                if (lane >= o && !head) {
-                    vx += x2;
-                    vy += y2;
-                    head |= h2;
-                }
-            }
+            const unsigned kprev = (unsigned)dpp_i<kDppWaveShr1>((int)~key, (int)key);  // lane 0 sees ~key: always a head
+            const int head = (kprev != key || !valid) ? 1 : 0;
+            const int hnext = dpp_i<kDppWaveShl1>(1, head);  // lane 63 sees 1: always a tail
+            const int tail = hnext != 0;
+            seg_scan64(head, vx, vy, lane);
             if (valid && tail) {  // last lane of its run holds the run's sum
                 // cell of the run in the workgroup's accumulator: [bin][tile - tile0][pixel in tile]
                 const int ix = (int)(key & 0xFFFu), iy = (int)((key >> 12) & 0xFFFu), bin = (int)(key >> 24);
