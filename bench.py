@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--events", default="uniform", choices=["uniform", "structured"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (1-GPU box testing with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -127,8 +130,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     elif args.gpus != 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if world != args.gpus:
@@ -214,7 +222,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic (%s events, seed 46)" % args.events,
             "config": {"workload": cfg["desc"], "events_per_gpu": n, "image": [H, W], "motion_model": cfg["model"],
-                       "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}"},
+                       "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}",
+                       "collectives": None if world == 1 else f"{args.backend}: all-reduce(IWE) + all-reduce(grad) per evaluation"},
             "roofline": {"bound": "hbm", "kernel": {"vote": "k_vote (K1 warp + bilinear vote)", "grad": "k_grad (K3 gather + gradient)",
                                                     "stats": "k_stats (K2)", "gimage": "k_gimage (K2b)"}[dominant],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -672,9 +672,9 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, double *__restric
             } else if (in[u]) {
                 const unsigned p = base + (unsigned)u * stride;
                 const int r = (int)(p / (unsigned)W), c = (int)(p - (unsigned)r * (unsigned)W);
-                double gx, gy;
-                sobel8<float>(img, H, W, r, c, gx, gy);
-                v[0] += gx * gx + gy * gy;
+                float gx, gy;
+                sobel8_f32(img, H, W, r, c, gx, gy);
+                v[0] += (double)(gx * gx + gy * gy);
             }
         }
     }
@@ -707,7 +707,7 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
         const bool in = (i >= i0) && (i < H - i0) && (j >= i0) && (j < W - i0);
         G[p] = in ? (float)(coef * 2.0 * ((double)img[p] - mu) / (npix - 1.0)) : 0.f;
     } else {
-        G[p] = (float)(coef * (2.0 / npix) * sobel8_adj<float>(img, H, W, i0, i, j) / 8.0);
+        G[p] = (float)(coef * (2.0 / npix) / 8.0) * sobel8_adj_f32(img, H, W, i0, i, j);
     }
 }
 
