@@ -97,7 +97,7 @@ def cpu_baseline(cfg, ev, motion, budget_s=12.0):
         orc.objective(ev, motion, cfg["model"], size, cost=cfg["cost"], sigma=cfg["sigma"])
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 200:
+        if el > budget_s or reps >= 5000:
             break
     return {"value": ev.shape[0] * reps / el, "unit": "events/s", "cores": 1, "kind": "port",
             "sample": f"{reps} full evaluations (value+gradient) of the same {ev.shape[0]}-event workload, "
@@ -192,9 +192,20 @@ def main():
         elapsed = float(tmax.item())
     loss = float(res[0].item())
 
-    # instrumented pass: HIP events around every launch of the four hot kernel classes
+    # instrumented passes (after the timed region, same inputs): HIP events recorded on the launch stream
+    # around every launch of the four hot kernel classes.
+    #  (a) one launch per bracket: what an evaluation actually runs, but each bracket adds ~2.5 us of
+    #      marker / dispatch latency to kernels that only run ~8 us;
+    #  (b) REPEAT launches per bracket: amortises that latency -> the per-launch duration used for the
+    #      roofline (agrees with the rocprofv3 kernel durations under profiles/).
+    REPEAT = 8
     handle.set_profiling(True)
     for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof_single = handle.read_profile()
+    handle.set_profiling(True, repeat=REPEAT)
+    for _ in range(max(args.steps // 4, 10)):
         step()
     torch.cuda.synchronize()
     prof = handle.read_profile()
@@ -204,6 +215,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n * world * args.steps / elapsed
         per_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof.items()}  # us per launch
+        single_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof_single.items()}
         dominant = max(per_kernel, key=lambda k: per_kernel[k])
         ab = algorithmic_bytes(dominant, n, H, W, cfg["model"], T)
         achieved = ab / (per_kernel[dominant] * 1e-6) / 1e9 if per_kernel[dominant] > 0 else 0.0
@@ -229,8 +241,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.workload, dominant), "algorithmic_bytes_per_launch": ab,
                          "launch_us": per_kernel[dominant],
-                         "method": "HIP events on the launch stream, instrumented pass of the same K steps",
-                         "all_kernels_us": per_kernel,
+                         "method": "HIP events on the launch stream; each bracket holds %d back-to-back launches of the kernel "
+                                   "(instrumented pass after the timed region, same inputs)" % REPEAT,
+                         "all_kernels_us": per_kernel, "all_kernels_single_launch_bracket_us": single_kernel,
                          "evaluation_GBps": eval_bytes / (ms_per_step * 1e-3) / 1e9,
                          "evaluation_frac": eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "loss": loss,

@@ -183,8 +183,10 @@ class CMaxHandle:
         return result, grad
 
     # -- per-kernel timing (bench.py roofline) ---------------------------------------------------------
-    def set_profiling(self, enable: bool):
-        check(self._lib.cmax_set_profiling(self._h, int(bool(enable))))
+    def set_profiling(self, enable, repeat: int = 1):
+        """enable: bracket every hot launch with HIP events.  repeat > 1: issue each hot launch `repeat` times
+        inside its bracket (amortises the bracket's dispatch latency; TIMING ONLY, results are meaningless)."""
+        check(self._lib.cmax_set_profiling(self._h, (int(repeat) if repeat > 1 else 1) if enable else 0))
 
     def read_profile(self) -> Dict[str, Tuple[float, int]]:
         """{kernel class: (total ms, launches)} measured with HIP events on the launch stream."""

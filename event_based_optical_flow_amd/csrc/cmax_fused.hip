@@ -100,6 +100,7 @@ struct cmax_handle_s {
     int64_t bytes = 0;
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
     bool profiling = false;
+    int prof_repeat = 1;  // > 1: every hot launch is issued this many times inside its event bracket (timing only)
     std::vector<hipEvent_t> prof_ev[4];  // class -> [start0, stop0, start1, stop1, ...]
 };
 
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const in
     __shared__ int s_win[kWinCap + kWave];
     __shared__ int s_box[16];
     // the statistics accumulators of the image being filled are reset here (K2 follows in stream order)
-    if (stat_zero && blockIdx.x == 0 && threadIdx.x < 2 * 8) stat_zero[threadIdx.x] = 0.0;
+    if (stat_zero && blockIdx.x == 0 && threadIdx.x < 2 * 32) stat_zero[threadIdx.x] = 0.0;
     const int sidx = segment_of_block(nseg);
     if (sidx >= nseg) return;
 #if defined(CMAX_ABL) && CMAX_ABL == 3
@@ -558,21 +559,22 @@ __global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const in
 
 // ---------------------------------------------------------------------------------------------
 // K2: contrast statistics of one image (+ zeroing of the NEXT evaluation's vote image).
-//     Workgroup b adds its fp64 partials to sub-accumulator b % 8 of its slot:
+//     Workgroup b adds its fp64 partials to sub-accumulator b % 32 of its slot:
 //     stat[slot][sub][0] = sum x (variance) or sum gx^2+gy^2 (grad-mag), [1] = sum x^2.
 //     Same-address fp64 atomics serialise at ~12 ns each (they cost 47 us in the first version), so
-//     they are spread over 8 addresses and consumers add the 8 values.  The accumulators are zeroed
+//     they are spread over 32 addresses and consumers add the 32 values.  The accumulators are zeroed
 //     by workgroup 0 of the K1 launch that fills the image (stream order), so no memset node exists.
 // ---------------------------------------------------------------------------------------------
-constexpr int kStatBlocksMax = 256;
+constexpr int kStatBlocksMax = 512;
 constexpr int kStatSlots = 5;  // reference times 0..3, slot 4 = un-warped image
-constexpr int kStatSub = 8;    // sub-accumulators per slot
+constexpr int kStatSub = 32;   // sub-accumulators per slot
 constexpr int kStatStride = kStatSub * 2;
 
 struct ObjParams {
     int cost, normalized, minimize, negate, omit, n_ref;
     double mult[4];
     int H, W;  // padded image
+    int nsub;  // sub-accumulators in use (<= kStatSub), grows with the number of k_stats workgroups
 };
 
 // raw contrast from the summed accumulators (variance: unbiased like torch.var, image_variance.py:55)
@@ -591,11 +593,10 @@ __device__ __forceinline__ double region_pixels(int H, int W, int omit) {
 }
 
 // sum of the sub-accumulators of one slot
-__device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int slot, double (&acc)[2]) {
+__device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int slot, int nsub, double (&acc)[2]) {
     acc[0] = 0.0;
     acc[1] = 0.0;
-#pragma unroll
-    for (int u = 0; u < kStatSub; ++u) {
+    for (int u = 0; u < nsub; ++u) {
         acc[0] += stat[slot * kStatStride + 2 * u];
         acc[1] += stat[slot * kStatStride + 2 * u + 1];
     }
@@ -605,7 +606,7 @@ __device__ __forceinline__ double orig_value(const ObjParams &op, const double *
     // orig_iwe is NOT boundary-cropped for the variance (normalized_image_variance.py:40-41)
     const int omit_o = op.cost == CMAX_COST_VARIANCE ? 0 : op.omit;
     double acc[2];
-    stat_sum(stat, 4, acc);
+    stat_sum(stat, 4, op.nsub, acc);
     return contrast_value(op.cost, acc, region_pixels(op.H, op.W, omit_o), nullptr);
 }
 
@@ -613,7 +614,7 @@ __device__ __forceinline__ double orig_value(const ObjParams &op, const double *
 __device__ __forceinline__ double chain_coef(const ObjParams &op, const double *stat, int k, double *mu_out) {
     const double npix = region_pixels(op.H, op.W, op.omit);
     double acc[2];
-    stat_sum(stat, k, acc);
+    stat_sum(stat, k, op.nsub, acc);
     const double v = contrast_value(op.cost, acc, npix, mu_out);
     double coef;
     if (!op.normalized) coef = op.mult[k] * (op.minimize ? -1.0 : 1.0);
@@ -631,7 +632,7 @@ __device__ void write_result(const ObjParams &op, const double *stat, double *__
     double loss = 0.0;
     for (int k = 0; k < op.n_ref; ++k) {
         double acc[2];
-        stat_sum(stat, k, acc);
+        stat_sum(stat, k, op.nsub, acc);
         const double v = contrast_value(op.cost, acc, npix, nullptr);
         result[1 + k] = v;
         if (!op.normalized) loss += op.mult[k] * (op.minimize ? -v : v);
@@ -643,7 +644,7 @@ __device__ void write_result(const ObjParams &op, const double *stat, double *__
 
 template <int COST>
 __global__ void __launch_bounds__(256)
-k_stats(const float *__restrict__ img, int H, int W, int omit, double *__restrict__ stat_slot, float *__restrict__ zero_img) {
+k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot, float *__restrict__ zero_img) {
     __shared__ double smem[2 * 4];
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
@@ -680,7 +681,7 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, double *__restric
     }
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) {
-        double *a = stat_slot + 2 * (blockIdx.x % kStatSub);
+        double *a = stat_slot + 2 * (blockIdx.x % nsub);
         atomic_add(&a[0], v[0]);
         if (COST == CMAX_COST_VARIANCE) atomic_add(&a[1], v[1]);
     }
@@ -900,8 +901,10 @@ template <int MODEL>
 static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, float *img, double *stat_zero, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfVote, s);
-    if (h->has_frac) hipLaunchKernelGGL((k_vote<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
-    else hipLaunchKernelGGL((k_vote<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
+    for (int rep = 0; rep < h->prof_repeat; ++rep) {
+        if (h->has_frac) hipLaunchKernelGGL((k_vote<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
+        else hipLaunchKernelGGL((k_vote<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
+    }
 }
 
 template <int MODEL>
@@ -911,12 +914,14 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     ProfScope prof(h, kProfGrad, s);
 #define CMAX_LAUNCH_GRAD(FRAC, FOLD) \
     hipLaunchKernelGGL((k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result)
-    if (h->has_frac) {
-        if (fold) CMAX_LAUNCH_GRAD(true, true);
-        else CMAX_LAUNCH_GRAD(true, false);
-    } else {
-        if (fold) CMAX_LAUNCH_GRAD(false, true);
-        else CMAX_LAUNCH_GRAD(false, false);
+    for (int rep = 0; rep < h->prof_repeat; ++rep) {
+        if (h->has_frac) {
+            if (fold) CMAX_LAUNCH_GRAD(true, true);
+            else CMAX_LAUNCH_GRAD(true, false);
+        } else {
+            if (fold) CMAX_LAUNCH_GRAD(false, true);
+            else CMAX_LAUNCH_GRAD(false, false);
+        }
     }
 #undef CMAX_LAUNCH_GRAD
 }
@@ -992,14 +997,22 @@ static int stat_blocks(const cmax_handle_s *h) {
 }
 
 // statistics of `img` -> stat[slot] (accumulators zeroed by the K1 launch); optionally zero `zero_img`
+static int stat_subs(const cmax_handle_s *h) {
+    int n = stat_blocks(h) / 12;  // ~12 same-address atomics per accumulator
+    return n < 4 ? 4 : (n > kStatSub ? kStatSub : n);
+}
+
 static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, int slot, float *zero_img, hipStream_t s) {
     const int grid = stat_blocks(h);
+    const int nsub = stat_subs(h);
     double *stat_slot = h->d_stat + slot * kStatStride;
     ProfScope prof(h, kProfStats, s);
-    if (cost == CMAX_COST_VARIANCE)
-        hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, stat_slot, zero_img);
-    else
-        hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, stat_slot, zero_img);
+    for (int rep = 0; rep < h->prof_repeat; ++rep) {
+        if (cost == CMAX_COST_VARIANCE)
+            hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img);
+        else
+            hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img);
+    }
     CMAX_CHECK_LAUNCH();
     return 0;
 }
@@ -1271,6 +1284,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
     op.H = Hp;
     op.W = Wp;
+    op.nsub = stat_subs(h);
 
     // statistics of the un-warped image (slot 4) are cached per batch
     if (d->normalized) {
@@ -1325,10 +1339,12 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             float *Gk = d->sigma > 0 ? h->Gt : h->G;
             {
                 ProfScope prof(h, kProfGimage, s);
-                if (d->cost == CMAX_COST_VARIANCE)
-                    hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
-                else
-                    hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
+                for (int rep = 0; rep < h->prof_repeat; ++rep) {
+                    if (d->cost == CMAX_COST_VARIANCE)
+                        hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
+                    else
+                        hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
+                }
             }
             if (d->sigma > 0)
                 hipLaunchKernelGGL(k_blur3_adj<float>, dim3(div_up(npix, 256)), dim3(256), 0, s, Gk, Hp, Wp, (float)k0, (float)k1, h->G);
@@ -1402,8 +1418,10 @@ static void prof_clear(cmax_handle_s *h) {
 
 int cmax_set_profiling(cmax_handle_t h, int enable) {
     CMAX_REQUIRE(h != nullptr, "set_profiling");
+    CMAX_REQUIRE(enable >= 0 && enable <= 64, "set_profiling: 0 (off), 1 (bracket every launch) or 2..64 (repeat count)");
     prof_clear(h);
     h->profiling = enable != 0;
+    h->prof_repeat = enable > 1 ? enable : 1;
     return 0;
 }
 
@@ -1419,7 +1437,7 @@ int cmax_read_profile(cmax_handle_t h, double *total_ms_host, int64_t *count_hos
             tot += (double)ms;
         }
         total_ms_host[c] = tot;
-        count_host[c] = (int64_t)np;
+        count_host[c] = (int64_t)np * h->prof_repeat;
     }
     prof_clear(h);
     return 0;

@@ -227,7 +227,10 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, co
                           cmax_stream_t stream);
 
 /* Per-kernel-class timing for bench.py's roofline: when enabled every launch of the four hot kernels
- * is bracketed by HIP events ON THE LAUNCH STREAM.  cmax_read_profile synchronises on them, returns
+ * is bracketed by HIP events ON THE LAUNCH STREAM.  enable = 1: one launch per bracket (results stay
+ * valid; the bracket adds ~2.5 us of marker/dispatch latency to a ~8 us kernel).  enable = R in 2..64:
+ * every hot launch is issued R times back to back inside its bracket, which amortises that latency;
+ * TIMING ONLY -- votes and gradients are accumulated R times, so the evaluation's numbers are meaningless.  cmax_read_profile synchronises on them, returns
  * total milliseconds and launch counts for class 0 = K1 warp+vote, 1 = K2 contrast statistics,
  * 2 = K2b gradient image, 3 = K3 per-event gradient (host arrays of 4), and resets.           */
 int cmax_set_profiling(cmax_handle_t h, int enable);

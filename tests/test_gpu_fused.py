@@ -263,3 +263,40 @@ def test_bad_arguments_raise():
         E.CMaxHandle((5000, 40))
     with pytest.raises(ValueError):
         h.set_events(np.zeros((10, 3)))
+
+
+@pytest.mark.parametrize("model", ["2d-translation", "dense-flow"])
+def test_large_displacements_clip_the_lds_window(model):
+    """Displacements far beyond the LDS window (theta = 150 px over the batch, the optimiser's search
+    range in configs/*.yaml): votes / gradient reads outside the window take the global-memory path."""
+    size, n = (130, 173), 120_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=61)
+    if model == "2d-translation":
+        motion = np.array([150.0, -140.0])
+    else:
+        motion = E.utils.generate_smooth_flow(size, 150, grid=3, seed=62)
+    ref = orc.objective(ev, motion, model, size, cost="image_variance", sigma=0)
+    loss, grads, h = fused_eval(size, ev, motion, model, "image_variance", 0)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
+def test_repeated_evaluations_are_consistent():
+    """The handle double-buffers its vote images (K2 of evaluation e zeroes the images of e+1): many
+    evaluations with changing costs / motions must keep giving the single-shot answer."""
+    size = (64, 80)
+    ev = E.utils.generate_events(30_000, size[0], size[1], 0.0, 0.05, seed=63)
+    h = E.CMaxHandle(size).set_events(ev)
+    rng = np.random.default_rng(0)
+    descs = [E.make_descriptor("image_variance", "2d-translation"),
+             E.make_descriptor("multi_focal_normalized_gradient_magnitude", "2d-translation", sigma=1.0),
+             E.make_descriptor("normalized_image_variance", "2d-translation")]
+    for it in range(12):
+        d = descs[it % 3]
+        theta = rng.uniform(-20, 20, 2)
+        res, grad = h.evaluate(d, theta)
+        fresh = E.CMaxHandle(size).set_events(ev)
+        res2, grad2 = fresh.evaluate(d, theta)
+        assert abs(res[0].item() - res2[0].item()) <= 1e-6 * abs(res2[0].item())
+        assert rel_max(grad.cpu().numpy(), grad2.cpu().numpy()) <= 1e-5
