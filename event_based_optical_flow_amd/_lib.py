@@ -64,6 +64,7 @@ SIGNATURES = {
     "cmax_vote_bwd": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_dbl, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_vp,
                               c_vp, c_vp]),
     "cmax_blur3": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_int, c_vp, c_vp]),
+    "cmax_gaussian_filter": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_vp, c_vp]),
     "cmax_contrast": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "cmax_total_variation": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "cmax_flow_step": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_int, c_vp, c_vp]),

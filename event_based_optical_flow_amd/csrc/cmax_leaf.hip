@@ -390,6 +390,35 @@ k_tv_final(const T *__restrict__ flow, int h, int w, int crop, double *acc, T *_
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
 // ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+// numpy-branch blur: scipy.ndimage.gaussian_filter(image, sigma) (src/event_image_converter.py:122-124)
+// radius = int(4 sigma + 0.5), weights exp(-t^2 / (2 sigma^2)) normalised, 'reflect' (edge-duplicating)
+// boundary, one 1-D pass per axis (axis 0 first).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int refl_dup(int i, int n) {
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i - 1;
+        if (i >= n) i = 2 * n - 1 - i;
+    }
+    return i;
+}
+
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256) k_gauss1d(const T *__restrict__ in, int H, int W, T inv2s2, int r, T *__restrict__ out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int i = (int)(p / W), j = (int)(p % W);
+    T acc = 0, norm = 0;
+    for (int t = -r; t <= r; ++t) {
+        const T w = (T)exp(-(double)((T)(t * t) * inv2s2));
+        norm += w;
+        const int q = AXIS == 0 ? refl_dup(i + t, H) * W + j : i * W + refl_dup(j + t, W);
+        acc += w * in[q];
+    }
+    out[p] = acc / norm;
+}
+
 }  // namespace cmax
 
 using namespace cmax;
@@ -523,6 +552,19 @@ int cmax_total_variation(const void *flow, int dtype, int h, int w, int omit_bou
     const int64_t npix = 2 * (int64_t)h * w;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_tv_sums<T>, dim3(stream_grid(npix, 256)), dim3(256), 0, s, (const T *)flow, h, w, crop, value));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_tv_final<T>, dim3(G ? div_up(npix, 256) : 1), dim3(256), 0, s, (const T *)flow, h, w, crop, value, (T *)G, gscale));
+    CMAX_CHECK_LAUNCH();
+    return 0;
+}
+
+int cmax_gaussian_filter(const void *in, int dtype, int H, int W, double sigma, void *tmp, void *out, cmax_stream_t stream) {
+    CMAX_REQUIRE(in && tmp && out && in != tmp && tmp != out && H > 0 && W > 0 && sigma > 0, "gaussian_filter");
+    const int r = (int)(4.0 * sigma + 0.5);
+    CMAX_REQUIRE(r <= 64, "gaussian_filter: sigma too large (radius > 64)");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = div_up((int64_t)H * W, 256);
+    const double inv2s2 = 0.5 / (sigma * sigma);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((k_gauss1d<T, 0>), dim3(grid), dim3(256), 0, s, (const T *)in, H, W, (T)inv2s2, r, (T *)tmp));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((k_gauss1d<T, 1>), dim3(grid), dim3(256), 0, s, (const T *)tmp, H, W, (T)inv2s2, r, (T *)out));
     CMAX_CHECK_LAUNCH();
     return 0;
 }

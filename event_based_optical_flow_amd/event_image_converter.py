@@ -1,10 +1,9 @@
 """`EventImageConverter`: events -> image of (warped) events, the reference's class
 (src/event_image_converter.py) over the HIP kernels cmax_vote / cmax_vote_bwd / cmax_blur3.
 
-numpy inputs use the numpy branch's floor epsilon (1e-8, line 282) and torch inputs the torch
-branch's (1e-6, line 340).  The blur is the torch branch's 3-tap reflect-101 Gaussian (153-159);
-the numpy branch's scipy.ndimage.gaussian_filter (122-124) is not built and raises
-NotImplementedError for sigma > 0 (out of scope: used only by the Optuna initialiser).
+numpy inputs use the numpy branch's floor epsilon (1e-8, line 282) and blur
+(scipy.ndimage.gaussian_filter restated as cmax_gaussian_filter, 122-124); torch inputs the torch
+branch's epsilon (1e-6, line 340) and 3-tap reflect-101 Gaussian (153-159).
 """
 import logging
 from typing import Optional, Tuple, Union
@@ -79,10 +78,14 @@ class EventImageConverter(object):
             logger.error(e)
             raise NotImplementedError(e)
         if sigma > 0:
-            e = ("numpy-branch blur (scipy gaussian_filter, 9 taps) is not built on the GPU; pass a torch tensor "
-                 "for the 3-tap blur or sigma=0")
-            logger.error(e)
-            raise NotImplementedError(e)
+            # scipy.ndimage.gaussian_filter(image, sigma) on the GPU.  The reference filters EVERY axis, so a
+            # batch or the 2-channel "polarity" stack would also be blurred across images (line 123); that
+            # quirk is not reproduced.
+            if image.ndim != 2:
+                e = "numpy-branch blur is built for one [H, W] image (the reference also blurs across the batch axis)"
+                logger.error(e)
+                raise NotImplementedError(e)
+            image = F.gaussian_filter(to_device_tensor(image, "image"), sigma).cpu().numpy()
         return image
 
     def create_image_from_events_tensor(self, events: torch.Tensor, method: str = "bilinear_vote",

@@ -333,3 +333,14 @@ def patch_to_dense(motion, image_size, sliding_window, pad):
     motion = _cuda(motion, "motion")
     return _PatchToDenseFn.apply(motion, (int(image_size[0]), int(image_size[1])),
                                  (int(sliding_window[0]), int(sliding_window[1])), (int(pad[0]), int(pad[1])))
+
+
+def gaussian_filter(img, sigma):
+    """scipy.ndimage.gaussian_filter of one [H,W] image (numpy branch of the reference's create_iwe,
+    src/event_image_converter.py:122-124).  Not differentiable (the numpy branch never is)."""
+    _lib.require_gpu()
+    img = _cuda(img.detach(), "image")
+    tmp, out = torch.empty_like(img), torch.empty_like(img)
+    check(_lib.load().cmax_gaussian_filter(_ptr(img), _code(img), img.shape[0], img.shape[1], float(sigma), _ptr(tmp),
+                                           _ptr(out), _stream()))
+    return out

@@ -118,6 +118,12 @@ int cmax_vote_bwd(const void *xy, int dtype, int64_t stride, int64_t n, const vo
 int cmax_blur3(const void *in, int dtype, int H, int W, double sigma, int adjoint, void *out,
                cmax_stream_t stream);
 
+/* numpy-branch blur of create_image_from_events_numpy (src/event_image_converter.py:122-124):
+ * scipy.ndimage.gaussian_filter(image, sigma) -- radius int(4 sigma + 0.5), edge-duplicating 'reflect'
+ * boundary, axis 0 then axis 1.  tmp: scratch image of the same size.                          */
+int cmax_gaussian_filter(const void *in, int dtype, int H, int W, double sigma, void *tmp, void *out,
+                         cmax_stream_t stream);
+
 /* ImageVariance.calculate / GradientMagnitude.calculate (src/costs/image_variance.py:27-71,
  * src/costs/gradient_magnitude.py:60-76 + SobelTorch src/utils/stat_utils.py:50-83).
  *   value  : device double[4]: value[0] = the RAW contrast (no sign), value[1..3] = scratch

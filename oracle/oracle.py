@@ -505,3 +505,11 @@ def solver_objective(events, x, image_size, patch_image_size, patch_size, slidin
     if res["grad_flow"] is not None:
         g = g + res["grad_flow"]
     return res["loss"], g.reshape(-1)
+
+
+def gaussian_filter(img, sigma):
+    """numpy-branch blur: scipy.ndimage.gaussian_filter restated (src/event_image_converter.py:122-124)."""
+    img = _f64(img)
+    out = np.empty_like(img)
+    lib().orc_gaussian_filter(_p(img), img.shape[0], img.shape[1], ctypes.c_double(sigma), _p(out))
+    return out

@@ -382,3 +382,22 @@ def gen_solver_objective(rng):
 
 if __name__ == "__main__" and "--solver-only" in sys.argv:
     gen_solver_objective(np.random.default_rng(SEED + 1))
+
+
+def gen_blur_numpy():
+    """numpy-branch create_iwe(sigma>0) = scipy gaussian_filter (real scipy, no shim) -> blur_numpy.npz"""
+    rng = np.random.default_rng(47)
+    H, W = 20, 30
+    xy = np.stack([rng.uniform(-1, H, 800), rng.uniform(-1, W, 800)], 1)
+    ev = np.concatenate([xy, np.zeros((800, 2))], 1)
+    im = event_image_converter.EventImageConverter((H, W))
+    out = {"events": ev, "image_size": np.array([H, W])}
+    for s in (1, 2, 0.6):
+        out[f"iwe_numpy_s{s}"] = im.create_iwe(ev, "bilinear_vote", s)
+    out["shims"] = np.array("none (scipy.ndimage.gaussian_filter is the real one)")
+    out["seed"] = np.array(47)
+    np.savez_compressed(os.path.join(HERE, "blur_numpy.npz"), **out)
+
+
+if __name__ == "__main__" and "--blur-numpy-only" in sys.argv:
+    gen_blur_numpy()

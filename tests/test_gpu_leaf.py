@@ -312,3 +312,13 @@ def test_motion_model_errors():
         warper.warp_event(ev, torch.zeros(2, device=DEV), "affine")
     with pytest.raises(ValueError):
         warper.warp_event(ev, torch.zeros(2, device=DEV), "2d-translation", direction="sideways")
+
+
+@pytest.mark.parametrize("sigma", [1, 2, 0.6])
+def test_numpy_branch_blur_golden(golden, sigma):
+    """create_iwe on numpy events with sigma > 0 = scipy.ndimage.gaussian_filter (reference line 122-124)."""
+    g = golden("blur_numpy")
+    size = tuple(int(v) for v in g["image_size"])
+    iwe = E.EventImageConverter(size).create_iwe(g["events"], "bilinear_vote", sigma)
+    assert isinstance(iwe, np.ndarray)
+    np.testing.assert_allclose(iwe, g[f"iwe_numpy_s{sigma}"], rtol=1e-10, atol=1e-13)

@@ -191,3 +191,11 @@ def test_solver_objective(golden, tag, scale):
     np.testing.assert_allclose(loss, g[k + "__loss"], rtol=1e-10)
     ref = g[k + "__grad"]
     np.testing.assert_allclose(grad, ref, rtol=1e-7, atol=1e-10 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("sigma", [1, 2, 0.6])
+def test_numpy_branch_blur(golden, sigma):
+    g = golden("blur_numpy")
+    size = tuple(int(v) for v in g["image_size"])
+    img = orc.vote(g["events"], size, eps=1e-8)
+    np.testing.assert_allclose(orc.gaussian_filter(img, sigma), g[f"iwe_numpy_s{sigma}"], rtol=1e-11, atol=1e-13)
