@@ -78,6 +78,7 @@ SIGNATURES = {
     "cmax_set_time_bins": (c_int, [c_vp, c_int, c_vp]),
     "cmax_iwe": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_vp, c_vp]),
     "cmax_objective": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
+    "cmax_objective_hvp": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_vote": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "cmax_sizeof_objective": (c_int, []),

@@ -155,6 +155,23 @@ class CMaxHandle:
                                        grad.data_ptr() if grad is not None else None, F._stream()))
         return result, grad
 
+    def hvp(self, desc: CmaxObjective, motion, tangent) -> torch.Tensor:
+        """Exact Hessian-vector product H @ tangent of the objective w.r.t. the motion (cmax_objective_hvp):
+        what torch.autograd.functional.vhp gives the reference's Newton-CG.  Returns fp64 [2] (2-DoF) or
+        fp32 with the motion's shape."""
+        m = self._motion32(motion)
+        u = to_device_tensor(tangent, "tangent").detach().to(torch.float64)
+        umax = u.abs().max()
+        if float(umax) == 0.0:
+            return torch.zeros(2, dtype=torch.float64, device=self.device) if desc.model == _lib.MODEL_2DOF else torch.zeros_like(m)
+        un = (u / umax).to(torch.float32).contiguous()  # unit max-norm: the derivative votes are fixed point
+        if desc.model == _lib.MODEL_2DOF:
+            hv = torch.empty(2, dtype=torch.float64, device=self.device)
+        else:
+            hv = torch.empty(tuple(m.shape), dtype=torch.float32, device=self.device)
+        check(self._lib.cmax_objective_hvp(self._h, ctypes.byref(desc), m.data_ptr(), un.data_ptr(), hv.data_ptr(), F._stream()))
+        return hv * umax.to(hv.dtype)
+
     # -- phase-split form (time-sliced multi-GPU, see distributed.py) --------------------------------
     def objective_vote(self, desc: CmaxObjective, motion) -> torch.Tensor:
         """Raw votes of this handle's events: fp32 [n_images, Hp, Wp] (n_ref images, plus the un-warped
@@ -249,6 +266,26 @@ class ContrastObjective:
                                        handle.time_bin if F.MODEL_CODES[motion_model] == _lib.MODEL_VOXEL else 0,
                                        warp_direction)
                 self.terms.append((name, weight, desc))
+
+    @property
+    def has_exact_hvp(self) -> bool:
+        """True when H v is available from cmax_objective_hvp: every fused term with a numeric weight
+        (total_variation is piecewise linear: zero Hessian almost everywhere)."""
+        return all(weight != "inv" for _, weight, _ in self.terms)
+
+    def hvp(self, motion: torch.Tensor, vector: torch.Tensor) -> torch.Tensor:
+        """Exact Hessian-vector product w.r.t. `motion` (same shape/dtype as motion)."""
+        if not self.has_exact_hvp:
+            raise NotImplementedError("exact HVP is not built for 'inv'-weighted hybrid terms")
+        out = None
+        for name, weight, desc in self.terms:
+            if desc is None:
+                continue  # total_variation: zero a.e.
+            hv = self.handle.hvp(desc, motion, vector).to(torch.float64) * float(weight)
+            out = hv if out is None else out + hv
+        if out is None:
+            out = torch.zeros_like(vector, dtype=torch.float64)
+        return out.reshape(vector.shape).to(vector.dtype if vector.dtype.is_floating_point else torch.float64)
 
     def __call__(self, motion: torch.Tensor, coarse_flow: Optional[torch.Tensor] = None) -> torch.Tensor:
         loss = 0.0

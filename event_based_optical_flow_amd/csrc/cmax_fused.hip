@@ -97,6 +97,9 @@ struct cmax_handle_s {
     bool orig_valid = false;
     double orig_sigma = -1;
     int orig_cost = -1, orig_omit = -1;
+    double tmin_host = 0.0, tmax_host = 0.0;  // batch extremes (copied once per batch)
+    float *hvp_img = nullptr;                 // [6, Hp, Wp] scratch of cmax_objective_hvp (allocated on first use)
+    double *d_stat_tan = nullptr;             // [kStatStride] tangent statistics
     int64_t bytes = 0;
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
     bool profiling = false;
@@ -864,6 +867,257 @@ k_grad(EvView ev, WarpParams wp, const int4 *__restrict__ segs, int nseg, const 
     if (result && sidx == nseg - 1 && threadIdx.x == 0) write_result(op, stat, result);
 }
 
+// =============================================================================================
+// Exact Hessian-vector product (a18): what torch.autograd.functional.vhp returns for the
+// objective (src/solver/scipy_autograd/torch_wrapper.py:51-73) -- the derivative of the analytic
+// gradient along a tangent motion u with the pixel cells held fixed (floor has zero derivative):
+//   H u = sum_k [ phi_k'' dv_k J^T G0_k + phi_k' ( (dJ^T/dtheta u) G0_k + J^T (dG0_k/dI) J u ) ]
+//   T1 k_vote_tan   tangent image dI = J u        (votes with the derivatives of the 4 bilinear weights)
+//   T2 k_stats_tan  <G0, dI> and mean(dI)  ;  k_gimage_tan  G' = phi' dG0 + phi'' dv G0
+//   T3 k_grad_hvp   per event: mixed term M (da, db) with the current G + gather of G' -> J^T
+// The tangent is scaled to unit max-norm by the caller so the derivative votes fit fixed point.
+// =============================================================================================
+struct TanParams {
+    const float *u;  // tangent motion, same layout as the motion, scaled to |u|_inf = 1
+    float fix, inv_fix;  // fixed-point scale of the derivative votes
+};
+
+// (da, db) of cached event slot: d(x', y')/d(motion) . u
+template <int MODEL>
+__device__ __forceinline__ void tangent_delta(const WarpParams &wp, const TanParams &tp, float dt, unsigned key, float u0, float u1,
+                                              float &da, float &db) {
+    if (MODEL == CMAX_MODEL_2DOF) {
+        da = dt * u0;  // x' = x + dt * theta0
+        db = dt * u1;
+    } else {
+        const int hw = wp.H * wp.W;
+        const int ix = (int)(key & 0xFFFu), iy = (int)((key >> 12) & 0xFFFu), bin = (int)(key >> 24);
+        const int src = bin * 2 * hw + ix * wp.W + iy;
+        da = -dt * tp.u[src];  // x' = x - dt * F[0, ix, iy]
+        db = -dt * tp.u[src + hw];
+    }
+}
+
+template <int MODEL, bool FRAC>
+__global__ void __launch_bounds__(256) k_vote_tan(EvView ev, WarpParams wp, TanParams tp, const int4 *__restrict__ segs, int nseg,
+                                                  float *__restrict__ dimg, double *__restrict__ stat_zero) {
+    __shared__ int s_win[kWinCap + kWave];
+    __shared__ int s_box[16];
+    if (stat_zero && blockIdx.x == 0 && threadIdx.x < 2 * 32) stat_zero[threadIdx.x] = 0.0;
+    const int sidx = segment_of_block(nseg);
+    if (sidx >= nseg) return;
+    const int4 sg = segs[sidx];
+    unsigned rc[kEPT];
+    float fa[kEPT], fb[kEPT], fdt[kEPT];
+    int fsrc[kEPT];
+    const Window win = phase_warp<MODEL, FRAC, true>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
+    float u0 = 0.f, u1 = 0.f;
+    if (MODEL == CMAX_MODEL_2DOF) {
+        u0 = tp.u[0];
+        u1 = tp.u[1];
+    }
+    const int wn = win.h << win.sh;
+    for (int i = threadIdx.x; i < wn; i += 256) s_win[i] = 0;
+    __syncthreads();
+    const int dummy = kDummy + (int)(threadIdx.x & (kWave - 1));
+#pragma unroll
+    for (int u = 0; u < kEPT; ++u) {
+        const bool valid = rc[u] != 0u;
+        const int row = (int)(rc[u] >> 16) - 16384, col = (int)(rc[u] & 0xFFFFu) - 16384;
+        const float a = fa[u], b = fb[u], na = 1.f - a, nb = 1.f - b;
+        float da = 0.f, db = 0.f;
+        if (valid) tangent_delta<MODEL>(wp, tp, fdt[u], (unsigned)fsrc[u], u0, u1, da, db);
+        // derivatives of w00 = na nb, w10 = a nb, w01 = na b, w11 = a b along (da, db)
+        const float d00 = -nb * da - na * db, d10 = nb * da - a * db, d01 = -b * da + na * db, d11 = b * da + a * db;
+        const int lr = row - win.r0, lc = col - win.c0;
+        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
+        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
+        const int base = (lr << win.sh) + lc, stride = 1 << win.sh;
+        atomicAdd(&s_win[(r_in0 && c_in0) ? base : dummy], (r_in0 && c_in0) ? __float2int_rn(d00 * tp.fix) : 0);
+        atomicAdd(&s_win[(r_in1 && c_in0) ? base + stride : dummy], (r_in1 && c_in0) ? __float2int_rn(d10 * tp.fix) : 0);
+        atomicAdd(&s_win[(r_in0 && c_in1) ? base + 1 : dummy], (r_in0 && c_in1) ? __float2int_rn(d01 * tp.fix) : 0);
+        atomicAdd(&s_win[(r_in1 && c_in1) ? base + stride + 1 : dummy], (r_in1 && c_in1) ? __float2int_rn(d11 * tp.fix) : 0);
+        if (win.clipped && valid) {
+            const float dv[4] = {d00, d10, d01, d11};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = row + (q & 1), c = col + (q >> 1);
+                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
+                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) atomic_add(&dimg[(int64_t)r * wp.Wp + c], dv[q]);
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int r = wave; r < win.h; r += 4) {
+        float *dst = dimg + (int64_t)(win.r0 + r) * wp.Wp + win.c0;
+        for (int c = lane; c < win.w; c += kWave) {
+            const int v = s_win[(r << win.sh) + c];
+            if (v != 0) atomic_add(&dst[c], (float)v * tp.inv_fix);
+        }
+    }
+}
+
+// T2a: st[0] += sum_Omega dI (variance) or sum_Omega (gx dgx + gy dgy) (grad-mag); st[1] += sum_Omega I dI
+template <int COST>
+__global__ void __launch_bounds__(256)
+k_stats_tan(const float *__restrict__ img, const float *__restrict__ dimg, int H, int W, int omit, int nsub, double *__restrict__ st) {
+    __shared__ double smem[2 * 4];
+    const unsigned npix = (unsigned)H * (unsigned)W;
+    const int i0 = omit ? 1 : 0;
+    double v[2] = {0.0, 0.0};
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+        const int r = (int)(p / (unsigned)W), c = (int)(p - (unsigned)r * (unsigned)W);
+        if (r < i0 || r >= H - i0 || c < i0 || c >= W - i0) continue;
+        if (COST == CMAX_COST_VARIANCE) {
+            const double d = (double)dimg[p];
+            v[0] += d;
+            v[1] += d * (double)img[p];
+        } else {
+            float gx, gy, hx, hy;
+            sobel8_f32(img, H, W, r, c, gx, gy);
+            sobel8_f32(dimg, H, W, r, c, hx, hy);
+            v[0] += (double)(gx * hx + gy * hy);
+        }
+    }
+    block_sum<2>(v, smem);
+    if (threadIdx.x == 0) {
+        double *a = st + 2 * (blockIdx.x % nsub);
+        atomic_add(&a[0], v[0]);
+        if (COST == CMAX_COST_VARIANCE) atomic_add(&a[1], v[1]);
+    }
+}
+
+// T2b: G'[p] = phi' * dG0[dI] + phi'' * dv * G0[I]   (stat: sums of I; st: tangent sums, slot-local pointer)
+template <int COST>
+__global__ void __launch_bounds__(256)
+k_gimage_tan(const float *__restrict__ img, const float *__restrict__ dimg, ObjParams op, int k, const double *__restrict__ stat,
+             const double *__restrict__ st, float *__restrict__ Gp) {
+    const int H = op.H, W = op.W, i0 = op.omit ? 1 : 0;
+    const double npix = region_pixels(H, W, op.omit);
+    double acc[2], tacc[2] = {0.0, 0.0};
+    stat_sum(stat, k, op.nsub, acc);
+    for (int u = 0; u < op.nsub; ++u) {
+        tacc[0] += st[2 * u];
+        tacc[1] += st[2 * u + 1];
+    }
+    double mu = 0.0;
+    const double v = contrast_value(COST, acc, npix, &mu);
+    // phi(v): loss contribution of this reference time; phi' = chain factor, phi'' its derivative
+    double p1, p2 = 0.0;
+    if (!op.normalized) p1 = op.mult[k] * (op.minimize ? -1.0 : 1.0);
+    else {
+        const double v_orig = orig_value(op, stat);
+        if (op.minimize) {
+            p1 = -op.mult[k] * v_orig / (v * v);
+            p2 = 2.0 * op.mult[k] * v_orig / (v * v * v);
+        } else p1 = op.mult[k] / v_orig;
+    }
+    if (op.negate) {
+        p1 = -p1;
+        p2 = -p2;
+    }
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int i = (int)(p / W), j = (int)(p % W);
+    if (COST == CMAX_COST_VARIANCE) {
+        const double dmean = tacc[0] / npix;
+        const double dv = 2.0 / (npix - 1.0) * (tacc[1] - mu * tacc[0]);  // <G0, dI>
+        const bool in = (i >= i0) && (i < H - i0) && (j >= i0) && (j < W - i0);
+        Gp[p] = in ? (float)((p1 * 2.0 * ((double)dimg[p] - dmean) + p2 * dv * 2.0 * ((double)img[p] - mu)) / (npix - 1.0)) : 0.f;
+    } else {
+        const double dv = 2.0 / npix * tacc[0];
+        const double c = (2.0 / npix) / 8.0;
+        Gp[p] = (float)(p1 * c) * sobel8_adj_f32(dimg, H, W, i0, i, j) + (float)(p2 * dv * c) * sobel8_adj_f32(img, H, W, i0, i, j);
+    }
+}
+
+// T3: per-event second-order gather.  G = dL/dIWE (current), Gp = its tangent.
+template <int MODEL, bool FRAC>
+__global__ void __launch_bounds__(256)
+k_grad_hvp(EvView ev, WarpParams wp, TanParams tp, const int4 *__restrict__ segs, int nseg, const float *__restrict__ G,
+           const float *__restrict__ Gp, double *__restrict__ gpart, float *__restrict__ hflow) {
+    __shared__ float s_g[kWinCap + kWave];
+    __shared__ float s_p[kWinCap + kWave];
+    __shared__ int s_box[16];
+    __shared__ double s_red[2 * 4];
+    const int sidx = segment_of_block(nseg);
+    if (sidx >= nseg) return;
+    const int4 sg = segs[sidx];
+    unsigned rc[kEPT];
+    float fa[kEPT], fb[kEPT], fdt[kEPT];
+    int fsrc[kEPT];
+    const Window win = phase_warp<MODEL, FRAC, true>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
+    float u0 = 0.f, u1 = 0.f;
+    if (MODEL == CMAX_MODEL_2DOF) {
+        u0 = tp.u[0];
+        u1 = tp.u[1];
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int r = threadIdx.x / kWave; r < win.h; r += 4)
+        for (int c = lane; c < win.w; c += kWave) {
+            const int64_t q = (int64_t)(win.r0 + r) * wp.Wp + win.c0 + c;
+            s_g[(r << win.sh) + c] = G[q];
+            s_p[(r << win.sh) + c] = Gp[q];
+        }
+    if (threadIdx.x < kWave) {
+        s_g[kDummy + threadIdx.x] = 0.f;
+        s_p[kDummy + threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    const int hw = wp.H * wp.W;
+    const int dummy = kDummy + lane, stride = 1 << win.sh;
+    float accx = 0.f, accy = 0.f;
+#pragma unroll
+    for (int j = 0; j < kEPT; ++j) {
+        const bool valid = rc[j] != 0u;
+        const int row = (int)(rc[j] >> 16) - 16384, col = (int)(rc[j] & 0xFFFFu) - 16384;
+        const int lr = row - win.r0, lc = col - win.c0;
+        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
+        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
+        const int base = (lr << win.sh) + lc;
+        const int i00 = (r_in0 && c_in0) ? base : dummy, i10 = (r_in1 && c_in0) ? base + stride : dummy;
+        const int i01 = (r_in0 && c_in1) ? base + 1 : dummy, i11 = (r_in1 && c_in1) ? base + stride + 1 : dummy;
+        float g[4] = {s_g[i00], s_g[i10], s_g[i01], s_g[i11]};
+        float q[4] = {s_p[i00], s_p[i10], s_p[i01], s_p[i11]};
+        if (win.clipped && valid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = row + (t & 1), c = col + (t >> 1);
+                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
+                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) {
+                    g[t] = G[(int64_t)r * wp.Wp + c];
+                    q[t] = Gp[(int64_t)r * wp.Wp + c];
+                }
+            }
+        }
+        const float a = fa[j], b = fb[j], dt = fdt[j];
+        float da = 0.f, db = 0.f;
+        if (valid) tangent_delta<MODEL>(wp, tp, dt, (unsigned)fsrc[j], u0, u1, da, db);
+        const float mixed = (g[3] - g[2]) - (g[1] - g[0]);  // d gx / d b = d gy / d a
+        const float hx = mixed * db + (1.f - b) * (q[1] - q[0]) + b * (q[3] - q[2]);
+        const float hy = mixed * da + (1.f - a) * (q[2] - q[0]) + a * (q[3] - q[1]);
+        if (MODEL == CMAX_MODEL_2DOF) {
+            accx = fmaf(dt, hx, accx);
+            accy = fmaf(dt, hy, accy);
+        } else if (valid) {
+            const unsigned key = (unsigned)fsrc[j];
+            const int ix = (int)(key & 0xFFFu), iy = (int)((key >> 12) & 0xFFFu), bin = (int)(key >> 24);
+            const int64_t o = (int64_t)bin * 2 * hw + (int64_t)ix * wp.W + iy;
+            atomic_add(&hflow[o], -dt * hx);  // the HVP runs once per CG step: plain per-event atomics are enough
+            atomic_add(&hflow[o + hw], -dt * hy);
+        }
+    }
+    if (MODEL == CMAX_MODEL_2DOF) {
+        double acc[2] = {(double)accx, (double)accy};
+        block_sum<2>(acc, s_red);
+        if (threadIdx.x == 0) {
+            gpart[2 * sidx] = acc[0];
+            gpart[2 * sidx + 1] = acc[1];
+        }
+    }
+}
+
 // 2-DoF only: gradient = sum of the per-segment partials of every K3 launch (one workgroup).
 __global__ void __launch_bounds__(256)
 k_finish(const double *__restrict__ gpart, int n_gpart, double *__restrict__ gtheta) {
@@ -1069,6 +1323,8 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->Gt);
     dev_free(&h->d_tmm);
     dev_free(&h->d_stat);
+    dev_free(&h->hvp_img);
+    dev_free(&h->d_stat_tan);
     dev_free(&h->d_gpart);
     dev_free(&h->counts);
     dev_free(&h->cursor);
@@ -1143,11 +1399,15 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     CMAX_CHECK_LAUNCH();
     int flags[2] = {0, 0};
     std::vector<int> tile_start((size_t)ntiles + 1);
+    double tmm_host[2] = {0.0, 0.0};
+    CMAX_CHECK_HIP(hipMemcpyAsync(tmm_host, h->d_tmm, sizeof(tmm_host), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipMemcpyAsync(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipMemcpyAsync(tile_start.data(), h->d_tile_start, tile_start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
     h->has_frac = flags[0] != 0;
     h->n = n - flags[1];
+    h->tmin_host = tmm_host[0];
+    h->tmax_host = tmm_host[1];
     // Segments: consecutive tiles of one tile row are merged while they fit (sparse batches), a dense
     // tile is split into several segments; never more than kSegMax events (fixed-point range).
     // max tiles per segment: the flow-gradient accumulator of the dense / voxel K3 holds
@@ -1404,6 +1664,146 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *moti
     if (rc) return rc;
     h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
     h->cur_buf ^= 1;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace cmax {
+
+// tangent votes of one reference time into `draw` (zeroed here)
+template <int MODEL>
+static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, float *draw, hipStream_t s) {
+    const int grid = 8 * ((h->nseg + 7) / 8);
+    if (h->has_frac) hipLaunchKernelGGL((k_vote_tan<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+    else hipLaunchKernelGGL((k_vote_tan<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+}
+
+template <int MODEL>
+static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, const float *G,
+                            const float *Gp, double *gpart, float *hflow, hipStream_t s) {
+    const int grid = 8 * ((h->nseg + 7) / 8);
+    if (h->has_frac) hipLaunchKernelGGL((k_grad_hvp<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    else hipLaunchKernelGGL((k_grad_hvp<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+}
+
+}  // namespace cmax
+
+extern "C" {
+
+int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *tangent, void *hv,
+                       cmax_stream_t stream) {
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(tangent && hv, "objective_hvp: tangent / hv");
+    hipStream_t s = (hipStream_t)stream;
+    const int Hp = h->Hp, Wp = h->Wp;
+    const int64_t npix = (int64_t)Hp * Wp;
+    const bool two_dof = d->model == CMAX_MODEL_2DOF;
+    const int64_t gcount = two_dof ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
+    const size_t gbytes = two_dof ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
+    CMAX_CHECK_HIP(hipMemsetAsync(hv, 0, gbytes, s));
+    if (h->n == 0) return 0;
+    if (!h->hvp_img) {
+        rc = dev_alloc(h, &h->hvp_img, 6 * npix);
+        if (!rc) rc = dev_alloc(h, &h->d_stat_tan, kStatStride);
+        if (rc) return rc;
+    }
+    float *I = h->hvp_img, *Ib = I + npix, *dI = I + 2 * npix, *dIb = I + 3 * npix, *Gp = I + 4 * npix, *Gpt = I + 5 * npix;
+
+    ObjParams op;
+    op.cost = d->cost;
+    op.normalized = d->normalized;
+    op.minimize = d->minimize;
+    op.negate = d->negate;
+    op.omit = d->omit_boundary;
+    op.n_ref = d->n_ref;
+    for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
+    op.H = Hp;
+    op.W = Wp;
+    op.nsub = stat_subs(h);
+    const int nsub = op.nsub;
+
+    // statistics of the un-warped image (slot 4), cached per batch like in cmax_objective
+    if (d->normalized && !orig_cache_hit(h, d)) {
+        rc = vote_image(h, -1, nullptr, 0, CMAX_REF_FIRST, 0.0, 1, I, false, 4, s);
+        if (rc) return rc;
+        const float *img = nullptr;
+        rc = blur_image(h, d->sigma, I, Ib, &img, s);
+        if (rc) return rc;
+        const int omit_o = d->cost == CMAX_COST_VARIANCE ? 0 : d->omit_boundary;
+        rc = launch_stats(h, d->cost, img, omit_o, 4, nullptr, s);
+        if (rc) return rc;
+        h->orig_valid = true;
+        h->orig_sigma = d->sigma;
+        h->orig_cost = d->cost;
+        h->orig_omit = d->omit_boundary;
+    }
+
+    // derivative votes are bounded by 2 |dt|_max (the tangent has unit max-norm): fixed-point scale
+    const double period = d->normalize_t ? 1.0 : (h->tmax_host - h->tmin_host);
+    const EvView ev = ev_view(h);
+    double k0 = 0, k1 = 0;
+    if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
+    const int igrid = div_up(npix, 256);
+    for (int k = 0; k < d->n_ref; ++k) {
+        const double dref = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        double dtmax = fabs(dref) > fabs(1.0 - dref) ? fabs(dref) : fabs(1.0 - dref);
+        dtmax *= period > 0 ? period : 1.0;
+        if (dtmax < 1e-30) dtmax = 1e-30;
+        TanParams tp;
+        tp.u = tangent;
+        tp.fix = (float)(1073741824.0 / ((double)kSegMax * 2.0 * dtmax));  // 2^30 / (events * max |derivative vote|)
+        tp.inv_fix = 1.f / tp.fix;
+        const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t);
+        // image, its blur and statistics (slot k)
+        rc = vote_image(h, d->model, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t, I, false, k, s);
+        if (rc) return rc;
+        const float *img = nullptr;
+        rc = blur_image(h, d->sigma, I, Ib, &img, s);
+        if (rc) return rc;
+        rc = launch_stats(h, d->cost, img, d->omit_boundary, k, nullptr, s);
+        if (rc) return rc;
+        // T1: tangent image and its blur
+        CMAX_CHECK_HIP(hipMemsetAsync(dI, 0, npix * sizeof(float), s));
+        switch (d->model) {
+            case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, dI, s); break;
+            case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, dI, s); break;
+            default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, dI, s); break;
+        }
+        CMAX_CHECK_LAUNCH();
+        const float *dimg = nullptr;
+        rc = blur_image(h, d->sigma, dI, dIb, &dimg, s);
+        if (rc) return rc;
+        // T2: tangent statistics, G (current) and G' (tangent), blur transposes
+        const int sgrid = stat_blocks(h);
+        if (d->cost == CMAX_COST_VARIANCE) {
+            hipLaunchKernelGGL(k_stats_tan<CMAX_COST_VARIANCE>, dim3(sgrid), dim3(256), 0, s, img, dimg, Hp, Wp, d->omit_boundary, nsub, h->d_stat_tan);
+            hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(igrid), dim3(256), 0, s, img, op, k, h->d_stat, d->sigma > 0 ? h->Gt : h->G);
+            hipLaunchKernelGGL(k_gimage_tan<CMAX_COST_VARIANCE>, dim3(igrid), dim3(256), 0, s, img, dimg, op, k, h->d_stat, h->d_stat_tan, d->sigma > 0 ? Gpt : Gp);
+        } else {
+            hipLaunchKernelGGL(k_stats_tan<CMAX_COST_GRADMAG>, dim3(sgrid), dim3(256), 0, s, img, dimg, Hp, Wp, d->omit_boundary, nsub, h->d_stat_tan);
+            hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(igrid), dim3(256), 0, s, img, op, k, h->d_stat, d->sigma > 0 ? h->Gt : h->G);
+            hipLaunchKernelGGL(k_gimage_tan<CMAX_COST_GRADMAG>, dim3(igrid), dim3(256), 0, s, img, dimg, op, k, h->d_stat, h->d_stat_tan, d->sigma > 0 ? Gpt : Gp);
+        }
+        if (d->sigma > 0) {
+            hipLaunchKernelGGL(k_blur3_adj<float>, dim3(igrid), dim3(256), 0, s, h->Gt, Hp, Wp, (float)k0, (float)k1, h->G);
+            hipLaunchKernelGGL(k_blur3_adj<float>, dim3(igrid), dim3(256), 0, s, Gpt, Hp, Wp, (float)k0, (float)k1, Gp);
+        }
+        CMAX_CHECK_LAUNCH();
+        // T3
+        double *gpart = h->d_gpart + (int64_t)k * h->nseg * 2;
+        switch (d->model) {
+            case CMAX_MODEL_2DOF: launch_grad_hvp<CMAX_MODEL_2DOF>(h, ev, wp, tp, h->G, Gp, gpart, nullptr, s); break;
+            case CMAX_MODEL_DENSE: launch_grad_hvp<CMAX_MODEL_DENSE>(h, ev, wp, tp, h->G, Gp, nullptr, (float *)hv, s); break;
+            default: launch_grad_hvp<CMAX_MODEL_VOXEL>(h, ev, wp, tp, h->G, Gp, nullptr, (float *)hv, s); break;
+        }
+        CMAX_CHECK_LAUNCH();
+    }
+    if (two_dof) {
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)hv);
+        CMAX_CHECK_LAUNCH();
+    }
     return 0;
 }
 

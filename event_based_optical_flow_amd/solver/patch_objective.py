@@ -52,6 +52,29 @@ class PatchFlowObjective:
             dense = F.construct_dense_flow_voxel(dense, self.time_bin, self.flow_interpolation, self.t0_flow_location)
         return dense
 
+    @property
+    def has_exact_hvp(self) -> bool:
+        # patch -> dense is linear, so H_x = t^2 P^T H_flow P; the Burgers voxel chain is nonlinear and has no
+        # second-order adjoint yet (TorchWrapper then differences the analytic gradient)
+        return (not self.time_aware) and self.contrast.has_exact_hvp
+
+    def hvp(self, x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """Exact Hessian-vector product w.r.t. the patch motion x."""
+        if not self.has_exact_hvp:
+            raise NotImplementedError("exact HVP needs a time-ignorant objective")
+        x = x.to(self.handle.device)
+        v = v.to(self.handle.device)
+        shape = (2,) + self.patch_image_size
+        size, sw, pad = self.handle.image_size, self.sliding_window, self.pad
+        dense = F.patch_to_dense(x.detach().reshape(shape), size, sw, pad) * self.t_scale
+        vdense = F.patch_to_dense(v.detach().reshape(shape).to(x.dtype), size, sw, pad) * self.t_scale
+        hflow = self.contrast.hvp(dense, vdense).to(x.dtype)  # [2,H,W]
+        # adjoint of the (linear) interpolation: the backward of patch_to_dense applied to hflow
+        probe = x.detach().reshape(shape).clone().requires_grad_()
+        out = F.patch_to_dense(probe, size, sw, pad)
+        (hx,) = torch.autograd.grad(out, probe, grad_outputs=hflow.contiguous())
+        return (hx * self.t_scale).reshape(x.shape)
+
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         x = x.to(self.handle.device)
         return self.contrast(self.dense_flow(x), x.reshape((2,) + self.patch_image_size))

@@ -4,10 +4,14 @@ Role of the reference's `TorchWrapper` (src/solver/scipy_autograd/torch_wrapper.
 there from brunorigal/autograd-minimize): value + gradient through `torch.autograd.grad`, and a
 Hessian-vector product for Newton-CG / trust-* methods.
 
-The objective's backward pass is a hand-written HIP kernel (a torch.autograd.Function), so a
-double-backward (`vhp`) does not exist.  The Hessian-vector product is a central difference of the
-ANALYTIC gradient,  Hv ~ [g(x + h v) - g(x - h v)] / (2h),  h = hvp_eps * (1 + |x|_inf) / |v|_inf:
-two gradient evaluations per CG step (the reference's vhp costs 1.8-3.7 evaluations).
+The objective's backward pass is a hand-written HIP kernel (a torch.autograd.Function), so autograd
+cannot double-backward through it.  Hessian-vector products come from
+  * `func.hvp(x, v)` when the objective provides it: the exact product computed by
+    cmax_objective_hvp (tangent image / tangent gradient kernels) -- the quantity the reference obtains
+    from torch.autograd.functional.vhp; else
+  * a central difference of the ANALYTIC gradient, Hv ~ [g(x + h v) - g(x - h v)] / (2h),
+    h = hvp_eps * (1 + |x|_inf) / |v|_inf  (time-aware objectives: the Burgers chain has no
+    second-order adjoint yet).
 """
 from typing import Callable, Sequence, Tuple
 
@@ -63,5 +67,8 @@ class TorchWrapper:
         vmax = np.abs(v).max()
         if vmax == 0.0:
             return np.zeros_like(v)
+        if self.hvp_type != "fd" and getattr(self.func, "has_exact_hvp", False):
+            hv = self.func.hvp(self._tensor(x, False), self._tensor(v, False))
+            return hv.detach().cpu().numpy().astype(np.float64).reshape(-1)
         h = self.hvp_eps * (1.0 + np.abs(x).max()) / vmax
         return (self.get_grad(x + h * v, *args) - self.get_grad(x - h * v, *args)) / (2.0 * h)

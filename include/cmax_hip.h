@@ -216,6 +216,15 @@ typedef struct {
 int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
                    double *result, void *grad, cmax_stream_t stream);
 
+/* Exact Hessian-vector product of the objective w.r.t. the motion, H u -- what
+ * torch.autograd.functional.vhp returns in the reference (src/solver/scipy_autograd/torch_wrapper.py:
+ * 51-73; the Hessian is symmetric): derivative of the analytic gradient along `tangent` with the
+ * bilinear cells held fixed.  tangent: fp32, same layout as motion, SCALED TO UNIT MAX-NORM by the
+ * caller (H is linear in u; the derivative votes are accumulated in fixed point).  hv: fp64 [2]
+ * (2DOF) or fp32 [2,H,W] / [T,2,H,W], overwritten.  Costs as in cmax_objective.                 */
+int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+                       const float *tangent, void *hv, cmax_stream_t stream);
+
 /* Phase-split form for time-sliced multi-GPU runs (one handle per GPU, each holding a contiguous
  * time slice of the batch and the GLOBAL tmin/tmax):
  *   cmax_objective_vote    raw votes of this slice: images[k] for k < n_ref, plus images[n_ref] =

@@ -318,20 +318,6 @@ def gen_hvp(rng):
          image_size=np.array([H, W]))
 
 
-if __name__ == "__main__" and "--solver-only" not in sys.argv:
-    torch.manual_seed(SEED)
-    np.random.seed(SEED)
-    rng = np.random.default_rng(SEED)
-    gen_known_answers()
-    gen_warps(rng)
-    gen_votes(rng)
-    gen_costs(rng)
-    gen_flow_voxel(rng)
-    gen_objectives(rng)
-    gen_hvp(rng)
-    gen_solver_objective(np.random.default_rng(SEED + 1))
-
-
 def gen_solver_objective(rng):
     """Whole solver objective (the optimiser's `fun`): PyramidalPatchContrastMaximization.objective_scipy
     (src/solver/patch_contrast_pyramid.py:430-462) = patch -> dense interpolation (+ Burgers voxel) ->
@@ -380,10 +366,6 @@ def gen_solver_objective(rng):
     save("solver_objective", **out)
 
 
-if __name__ == "__main__" and "--solver-only" in sys.argv:
-    gen_solver_objective(np.random.default_rng(SEED + 1))
-
-
 def gen_blur_numpy():
     """numpy-branch create_iwe(sigma>0) = scipy gaussian_filter (real scipy, no shim) -> blur_numpy.npz"""
     rng = np.random.default_rng(47)
@@ -399,5 +381,61 @@ def gen_blur_numpy():
     np.savez_compressed(os.path.join(HERE, "blur_numpy.npz"), **out)
 
 
-if __name__ == "__main__" and "--blur-numpy-only" in sys.argv:
-    gen_blur_numpy()
+def gen_hvp_cases():
+    """vhp of the objective w.r.t. the motion (torch.autograd.functional.vhp, what Newton-CG receives,
+    src/solver/scipy_autograd/torch_wrapper.py:51-73) for the inputs of objective.npz -> hvp_cases.npz"""
+    g = dict(np.load(os.path.join(HERE, "objective.npz")))
+    H, W = (int(v) for v in g["image_size"])
+    te = torch.from_numpy(g["events"])
+    rng = np.random.default_rng(SEED + 2)
+    out = {}
+    cases = [("2dof", "2d-translation", "theta", c, s) for c, s in
+             (("image_variance", 0), ("image_variance", 1), ("gradient_magnitude", 1), ("normalized_image_variance", 1),
+              ("multi_focal_normalized_gradient_magnitude", 1))]
+    cases += [("dense_smooth", "dense-flow", "flow_smooth", c, 1) for c in
+              ("image_variance", "gradient_magnitude", "multi_focal_normalized_gradient_magnitude")]
+    cases += [("voxel", "dense-flow-voxel", "voxel", "image_variance", 1)]
+    for mname, model, mkey, cost_name, sigma in cases:
+        fs = _fake_solver(H, W, cost_name, sigma)
+
+        def f(m):
+            arg = PatchContrastMaximization.get_arg_for_cost(fs, te, m, model, None)
+            return fs.cost_func.calculate(arg)
+
+        x = torch.from_numpy(g[mkey])
+        v = torch.from_numpy(rng.normal(size=x.shape))
+        loss, hv = torch.autograd.functional.vhp(f, x, v)
+        tag = f"{mname}__{cost_name}__s{sigma}"
+        out[tag + "__v"] = v.numpy()
+        out[tag + "__vhp"] = hv.numpy()
+        out[tag + "__loss"] = np.array(loss.item())
+        print(tag, float(loss), float(hv.abs().max()))
+    out["shims"] = np.array(ref_import.SHIMS)
+    out["seed"] = np.array(SEED + 2)
+    np.savez_compressed(os.path.join(HERE, "hvp_cases.npz"), **out)
+
+
+def gen_core():
+    torch.manual_seed(SEED)
+    np.random.seed(SEED)
+    rng = np.random.default_rng(SEED)
+    gen_known_answers()
+    gen_warps(rng)
+    gen_votes(rng)
+    gen_costs(rng)
+    gen_flow_voxel(rng)
+    gen_objectives(rng)
+    gen_hvp(rng)
+
+
+if __name__ == "__main__":
+    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases]   (no argument = everything)
+    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases"]
+    if "core" in which:
+        gen_core()
+    if "solver" in which:
+        gen_solver_objective(np.random.default_rng(SEED + 1))
+    if "blur_numpy" in which:
+        gen_blur_numpy()
+    if "hvp_cases" in which:
+        gen_hvp_cases()

@@ -62,13 +62,13 @@ def test_solver_objective_golden(golden, tag, scale):
     assert rel_max(grad.cpu().numpy(), g[k + "__grad"]) <= TOL
 
 
-def test_hvp_is_the_difference_quotient_of_the_exact_gradient(golden):
-    """Newton-CG's hessp is a central difference of the analytic HIP gradient (TorchWrapper.get_hvp).
-    It is checked against the same difference quotient of the fp64 oracle gradient.  It is NOT
-    expected to equal the reference's autograd vhp (golden hvp.npz keeps that value for the exact
-    HVP kernel of SURVEY section 8f): autograd differentiates the bilinear weights inside fixed
-    pixel cells (floor has zero derivative), whereas a finite step lets events cross cell borders,
-    where the gradient of the tent-kernel vote jumps."""
+def test_hvp_exact_and_difference_quotient(golden):
+    """Newton-CG's hessp.  (i) Default: the exact product from cmax_objective_hvp == the reference's
+    torch.autograd.functional.vhp (golden hvp.npz).  (ii) hvp_type="fd" (the fallback of time-aware
+    objectives): a central difference of the analytic HIP gradient, checked against the same quotient
+    of the fp64 oracle gradient.  (i) and (ii) differ by nature: autograd differentiates the bilinear
+    weights inside fixed pixel cells (floor has zero derivative), whereas a finite step lets events
+    cross cell borders, where the gradient of the tent-kernel vote jumps."""
     g = golden("hvp")
     size = tuple(int(v) for v in g["image_size"])
     h = E.CMaxHandle(size).set_events(g["events"])
@@ -78,6 +78,9 @@ def test_hvp_is_the_difference_quotient_of_the_exact_gradient(golden):
     loss, _ = w.get_value_and_grad(x)
     assert abs(float(loss) - g["loss"]) <= TOL * abs(g["loss"])
     v = g["v"]
+    assert rel_max(w.get_hvp(x, v), g["vhp"]) <= 1e-4  # exact kernel vs the reference's vhp
+    w = TorchWrapper(obj, precision="float64", device="cuda", hvp_type="fd")
+    w.get_input(g["theta"])
     hv = w.get_hvp(x, v)
     step = w.hvp_eps * (1.0 + np.abs(x).max()) / np.abs(v).max()
 
@@ -102,3 +105,49 @@ def test_minimize_recovers_the_generating_velocity(method):
     # the optimum of the pixel-rounded, border-clipped event set sits within a fraction of a pixel of `vel`
     assert np.abs(res.x - vel).max() < 0.35, res
     assert np.linalg.norm(res.jac) < 0.05
+
+
+HVP_CASES = [("2dof", "2d-translation", "theta", c, s) for c, s in
+             (("image_variance", 0), ("image_variance", 1), ("gradient_magnitude", 1), ("normalized_image_variance", 1),
+              ("multi_focal_normalized_gradient_magnitude", 1))]
+HVP_CASES += [("dense_smooth", "dense-flow", "flow_smooth", c, 1) for c in
+              ("image_variance", "gradient_magnitude", "multi_focal_normalized_gradient_magnitude")]
+HVP_CASES += [("voxel", "dense-flow-voxel", "voxel", "image_variance", 1)]
+
+
+@pytest.mark.parametrize("mname,model,mkey,cost,sigma", HVP_CASES)
+def test_exact_hvp_against_reference_vhp(golden, mname, model, mkey, cost, sigma):
+    """cmax_objective_hvp vs torch.autograd.functional.vhp run on the reference (hvp_cases.npz).
+    Tolerance 1e-3 of the largest entry: fp32 events, fixed-point tangent votes."""
+    g, o = golden("hvp_cases"), golden("objective")
+    size = tuple(int(v) for v in o["image_size"])
+    tb = o[mkey].shape[0] if model == "dense-flow-voxel" else 0
+    h = E.CMaxHandle(size).set_events(o["events"], time_bin=tb)
+    obj = E.ContrastObjective(h, model, cost=cost, sigma=sigma)
+    tag = f"{mname}__{cost}__s{sigma}"
+    m = torch.tensor(o[mkey], dtype=torch.float64, device="cuda")
+    v = torch.tensor(g[tag + "__v"], dtype=torch.float64, device="cuda")
+    hv = obj.hvp(m, v).cpu().numpy()
+    assert rel_max(hv, g[tag + "__vhp"]) <= 1e-3, (np.abs(hv - g[tag + "__vhp"]).max(), np.abs(g[tag + "__vhp"]).max())
+
+
+def test_exact_hvp_through_the_patch_interpolation(golden):
+    """H_x v for the patch objective = t^2 P^T H_flow P v; checked against a difference quotient of the
+    exact gradient along v with a step small enough that (almost) no event changes its pixel cell."""
+    g = golden("solver_objective")
+    k = "plain_s3"
+    size = tuple(int(v) for v in g["image_size"])
+    ev = g["events"]
+    h = E.CMaxHandle(size).set_events(ev)
+    obj = PatchFlowObjective(h, ev[:, 2].max() - ev[:, 2].min(), g[k + "__patch_image_size"], g[k + "__patch_size"],
+                             g[k + "__sliding_window"], g["plain__patch_shift"], cost="hybrid", cost_with_weight=YAML_HYBRID,
+                             blur_sigma=1)
+    assert obj.has_exact_hvp
+    x = torch.tensor(g[k + "__x"], dtype=torch.float64, device="cuda")
+    v = torch.tensor(np.random.default_rng(3).normal(size=x.shape), dtype=torch.float64, device="cuda")
+    hv = obj.hvp(x, v).cpu().numpy()
+    w = TorchWrapper(obj, precision="float64", device="cuda", hvp_type="fd", hvp_eps=3e-6)
+    w.get_input(g[k + "__x"])
+    fd = w.get_hvp(g[k + "__x"], v.cpu().numpy())
+    # the quotient still sees a few cell crossings and fp32 gradient noise / step: agreement to a few per cent
+    assert np.abs(hv - fd).max() <= 0.1 * np.abs(fd).max(), (np.abs(hv - fd).max(), np.abs(fd).max())
