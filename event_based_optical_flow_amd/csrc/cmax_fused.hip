@@ -26,16 +26,9 @@ namespace cmax {
 
 constexpr int kTile = 16;  // source-pixel tile edge of the counting sort
 constexpr uint32_t kDropped = 0xFFFFFFFFu;
-#ifndef CMAX_EPT
-#define CMAX_EPT 8
-#endif
-#ifndef CMAX_WINCAP
-#define CMAX_WINCAP 8192
-#endif
-constexpr int kEPT = CMAX_EPT;                // events per thread (cached in registers between the two phases)
-constexpr int kSegMax = 256 * kEPT - 8;       // events per segment (+1 for the even-aligned start still fits 256*kEPT);
+constexpr int kSegMax = 2040;                 // events per segment (+1 for the even-aligned start still fits 2048);
                                               // |sum of votes| <= 2040 * 2^20 < 2^31
-constexpr int kWinCap = CMAX_WINCAP;          // LDS window capacity in 32-bit words (32 KiB)
+constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit words (32 KiB)
 static_assert(kSegMax <= 2040, "fixed-point vote accumulation would overflow");
 constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (dense / voxel K3)
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
@@ -359,207 +352,6 @@ __device__ __forceinline__ void seg_scan64(int head, float &vx, float &vy, int l
     }
 }  // 64 scratch words behind the window: target of masked lanes (branch-free phase B)
 
-// Phase A of both event kernels: warp this thread's <= kEPT events (kept in registers), reduce the
-// bounding box of their 2x2 vote footprints over the workgroup and derive the LDS window.
-// rc[j] packs (row + 16384) << 16 | (col + 16384); 0 marks an empty slot.
-template <int MODEL, bool FRAC, bool WANT_DT>
-__device__ __forceinline__ Window phase_warp(const EvView &ev, const WarpParams &wp, int4 sg, unsigned (&rc)[kEPT],
-                                              float (&fa)[kEPT], float (&fb)[kEPT], float (&fdt)[kEPT], int (&fsrc)[kEPT],
-                                              int *s_box) {
-    const float tscale = time_scale(wp);
-    float th0 = 0.f, th1 = 0.f;
-    if (MODEL == CMAX_MODEL_2DOF) {
-        th0 = wp.motion[0];
-        th1 = wp.motion[1];
-    }
-    int mnr = 0x7fffffff, mxr = -0x7fffffff, mnc = 0x7fffffff, mxc = -0x7fffffff;
-    // 16-byte loads: lane l of iteration j reads events base + 2*(256 j + l) + {0, 1}; `base` is the
-    // segment start rounded down to an even index (the buffer is 16-byte aligned and padded), slot
-    // u = 2 j + e.  Consecutive lanes read consecutive 16 B: one coalesced 4 KiB request per wave.
-    const int64_t base = (int64_t)sg.x & ~(int64_t)1;
-    const int64_t seg_end = (int64_t)sg.x + sg.y;
-    uint4 raw[kEPT / 2];
-#pragma unroll
-    for (int j = 0; j < kEPT / 2; ++j) {
-        const int64_t i0 = base + 2 * ((int64_t)j * 256 + threadIdx.x);
-        raw[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (i0 < seg_end) raw[j] = *reinterpret_cast<const uint4 *>(ev.ev + i0);
-    }
-#pragma unroll
-    for (int u = 0; u < kEPT; ++u) {
-        const int j = u >> 1;
-        const int64_t i = base + 2 * ((int64_t)j * 256 + threadIdx.x) + (u & 1);
-        const uint2 e = (u & 1) ? make_uint2(raw[j].z, raw[j].w) : make_uint2(raw[j].x, raw[j].y);
-        rc[u] = 0u;  // empty slot: finite defaults so masked arithmetic can never produce NaN
-        fa[u] = 0.f;
-        fb[u] = 0.f;
-        if (WANT_DT) {
-            fdt[u] = 0.f;
-            fsrc[u] = -1;
-        }
-        if (i >= sg.x && i < seg_end) {
-            const Warped w = warp_one<MODEL, FRAC>(ev, e, i, wp, tscale, th0, th1);
-            rc[u] = ((unsigned)(w.row + 16384) << 16) | (unsigned)(w.col + 16384);
-            fa[u] = w.a;
-            fb[u] = w.b;
-            if (WANT_DT) {
-                fdt[u] = w.dt;
-                // run key of the flow-gradient reduction: packed (row, col[, bin]) -- unique per cell, decoded by shifts
-                fsrc[u] = (int)(MODEL == CMAX_MODEL_VOXEL ? e.x : (e.x & 0x00FFFFFFu));
-            }
-            mnr = min(mnr, w.row);
-            mxr = max(mxr, w.row);
-            mnc = min(mnc, w.col);
-            mxc = max(mxc, w.col);
-        }
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mnr = min(mnr, __shfl_xor(mnr, o, kWave));
-        mxr = max(mxr, __shfl_xor(mxr, o, kWave));
-        mnc = min(mnc, __shfl_xor(mnc, o, kWave));
-        mxc = max(mxc, __shfl_xor(mxc, o, kWave));
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) {  // one slot of 4 ints per wave, combined by every thread after the barrier
-        const int wv = threadIdx.x / kWave;
-        s_box[4 * wv + 0] = mnr;
-        s_box[4 * wv + 1] = mxr;
-        s_box[4 * wv + 2] = mnc;
-        s_box[4 * wv + 3] = mxc;
-    }
-    __syncthreads();
-    const int bmnr = min(min(s_box[0], s_box[4]), min(s_box[8], s_box[12]));
-    const int bmxr = max(max(s_box[1], s_box[5]), max(s_box[9], s_box[13]));
-    const int bmnc = min(min(s_box[2], s_box[6]), min(s_box[10], s_box[14]));
-    const int bmxc = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
-    Window win;
-    // footprint rows [min, max + 1], clipped to the image
-    int r0 = max(bmnr, 0), r1 = min(bmxr + 2, wp.Hp);
-    int c0 = max(bmnc, 0), c1 = min(bmxc + 2, wp.Wp);
-    int h = max(r1 - r0, 0), w = max(c1 - c0, 0);
-    win.clipped = false;
-    if (w > kWinMaxW) {  // rare (very large displacements): keep the centre, the rest goes to global memory
-        c0 += (w - kWinMaxW) / 2;
-        w = kWinMaxW;
-        win.clipped = true;
-    }
-    int sh = 4;
-    while ((1 << sh) < w) ++sh;  // row stride 16 .. 128
-    const int hmax = kWinCap >> sh;
-    if (h > hmax) {
-        r0 += (h - hmax) / 2;
-        h = hmax;
-        win.clipped = true;
-    }
-    win.sh = sh;
-    win.r0 = r0;
-    win.c0 = c0;
-    win.h = h;
-    win.w = w;
-    return win;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1: warp + bilinear vote.  LDS window in signed 12.20 fixed point (ds_add_u32), coalesced flush.
-// ---------------------------------------------------------------------------------------------
-template <int MODEL, bool FRAC>
-__global__ void __launch_bounds__(256) k_vote(EvView ev, WarpParams wp, const int4 *__restrict__ segs, int nseg,
-                                              float *__restrict__ iwe, double *__restrict__ stat_zero) {
-    __shared__ int s_win[kWinCap + kWave];
-    __shared__ int s_box[16];
-    // the statistics accumulators of the image being filled are reset here (K2 follows in stream order)
-    if (stat_zero && blockIdx.x == 0 && threadIdx.x < 2 * 32) stat_zero[threadIdx.x] = 0.0;
-    const int sidx = segment_of_block(nseg);
-    if (sidx >= nseg) return;
-#if defined(CMAX_ABL) && CMAX_ABL == 3
-    return;
-#endif
-    const int4 sg = segs[sidx];
-#if defined(CMAX_ABL) && CMAX_ABL == 4
-    if (sg.x == -12345) iwe[0] = 1.f;
-    return;
-#endif
-#if defined(CMAX_ABL) && CMAX_ABL == 5
-    {
-        const int64_t base = (int64_t)sg.x & ~(int64_t)1;
-        uint4 acc4 = make_uint4(0, 0, 0, 0);
-        for (int j = 0; j < kEPT / 2; ++j) {
-            const int64_t i0 = base + 2 * ((int64_t)j * 256 + threadIdx.x);
-            if (i0 < (int64_t)sg.x + sg.y) { uint4 v = *reinterpret_cast<const uint4 *>(ev.ev + i0); acc4.x ^= v.x; acc4.y ^= v.y; acc4.z ^= v.z; acc4.w ^= v.w; }
-        }
-        if ((acc4.x ^ acc4.y ^ acc4.z ^ acc4.w) == 0x12345u) iwe[0] = 1.f;
-        return;
-    }
-#endif
-    unsigned rc[kEPT];
-    float fa[kEPT], fb[kEPT], fdt[kEPT];
-    int fsrc[kEPT];
-    const Window win = phase_warp<MODEL, FRAC, false>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
-#if defined(CMAX_ABL) && CMAX_ABL == 1
-    if (win.h == -12345) iwe[0] = fa[0] + fb[1] + (float)rc[2];
-    return;
-#endif
-    const int wn = win.h << win.sh;
-    for (int i = threadIdx.x; i < wn; i += 256) s_win[i] = 0;
-    __syncthreads();
-    // phase B: 4 votes per event, branch-free: a vote outside the window adds 0 to a per-lane scratch word
-    const int dummy = kDummy + (int)(threadIdx.x & (kWave - 1));
-#pragma unroll
-    for (int u = 0; u < kEPT; ++u) {
-        const int row = (int)(rc[u] >> 16) - 16384, col = (int)(rc[u] & 0xFFFFu) - 16384;  // empty slot: (-16384, -16384)
-        const float a = fa[u], b = fb[u], na = 1.f - a, nb = 1.f - b;
-        const int lr = row - win.r0, lc = col - win.c0;
-        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
-        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
-        const int base = (lr << win.sh) + lc;
-        const int stride = 1 << win.sh;
-        // w_pos0..3, event_image_converter.py:365-368
-        atomicAdd(&s_win[(r_in0 && c_in0) ? base : dummy], (r_in0 && c_in0) ? __float2int_rn(na * nb * kFix) : 0);
-        atomicAdd(&s_win[(r_in1 && c_in0) ? base + stride : dummy], (r_in1 && c_in0) ? __float2int_rn(a * nb * kFix) : 0);
-        atomicAdd(&s_win[(r_in0 && c_in1) ? base + 1 : dummy], (r_in0 && c_in1) ? __float2int_rn(na * b * kFix) : 0);
-        atomicAdd(&s_win[(r_in1 && c_in1) ? base + stride + 1 : dummy], (r_in1 && c_in1) ? __float2int_rn(a * b * kFix) : 0);
-    }
-    if (win.clipped) {  // workgroup-uniform, rare: votes outside the LDS window but inside the image
-#pragma unroll
-        for (int u = 0; u < kEPT; ++u) {
-            if (rc[u] == 0u) continue;
-            const int row = (int)(rc[u] >> 16) - 16384, col = (int)(rc[u] & 0xFFFFu) - 16384;
-            const float a = fa[u], b = fb[u], na = 1.f - a, nb = 1.f - b;
-            const float wv[4] = {na * nb, a * nb, na * b, a * b};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = row + (q & 1), c = col + (q >> 1);
-                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
-                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) atomic_add(&iwe[(int64_t)r * wp.Wp + c], wv[q]);
-            }
-        }
-    }
-    __syncthreads();
-#if defined(CMAX_ABL) && CMAX_ABL == 2
-    if (s_win[threadIdx.x] == -12345) iwe[0] = 1.f;
-    return;
-#endif
-    // flush: one coalesced global atomic per touched window pixel (a wave per window row)
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (win.w > 32) {
-        for (int r = wave; r < win.h; r += 4) {
-            float *dst = iwe + (int64_t)(win.r0 + r) * wp.Wp + win.c0;
-            for (int c = lane; c < win.w; c += kWave) {
-                const int v = s_win[(r << win.sh) + c];
-                if (v != 0) atomic_add(&dst[c], (float)v * kInvFix);
-            }
-        }
-    } else {  // narrow window: two rows per wave
-        const int half = lane >> 5, c = lane & 31;
-        for (int r = 2 * wave + half; r < win.h; r += 8) {
-            if (c < win.w) {
-                const int v = s_win[(r << win.sh) + c];
-                if (v != 0) atomic_add(&iwe[(int64_t)(win.r0 + r) * wp.Wp + win.c0 + c], (float)v * kInvFix);
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K2: contrast statistics of one image (+ zeroing of the NEXT evaluation's vote image).
 //     Workgroup b adds its fp64 partials to sub-accumulator b % 32 of its slot:
@@ -715,158 +507,6 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K3: per-event gradient, one workgroup per segment (same work list and window as K1).
-//     The dL/dIWE window is staged in LDS; per event
-//        dL/dx' = (1-b)(G10-G00) + b(G11-G01),  dL/dy' = (1-a)(G01-G00) + a(G11-G10)
-//     2-DoF : per-workgroup fp64 partial of sum dt*(gx, gy) -> gpart[block] (summed by k_finish)
-//     dense : -dt*g reduced over runs of equal source pixel inside the wave (events are sorted by
-//             pixel), one fp32 atomic per run and channel
-//     FOLD  : G is not materialised: G = c2 * (IWE - mu) on the cropped interior (variance, no blur)
-// ---------------------------------------------------------------------------------------------
-template <int MODEL, bool FRAC, bool FOLD>
-__global__ void __launch_bounds__(256)
-k_grad(EvView ev, WarpParams wp, const int4 *__restrict__ segs, int nseg, const float *__restrict__ img, ObjParams op, int k,
-       const double *__restrict__ stat, double *__restrict__ gpart, float *__restrict__ gflow, double *__restrict__ result) {
-    __shared__ float s_win[kWinCap + kWave];
-    __shared__ int s_box[16];
-    __shared__ double s_red[2 * 4];
-    // flow-gradient accumulators (x | y): voxel only -- measured on MI355X the dense model is faster with one
-    // global atomic per run (its runs are long and LDS occupancy matters more), the voxel model with LDS
-    constexpr bool kLdsAcc = MODEL == CMAX_MODEL_VOXEL;
-    __shared__ float s_acc[kLdsAcc ? 2 * kAccCells : 1];
-    const int sidx = segment_of_block(nseg);
-    if (sidx >= nseg) return;
-    const int4 sg = segs[sidx];
-    if (kLdsAcc) {
-        for (int i = threadIdx.x; i < 2 * kAccCells; i += 256) s_acc[i] = 0.f;  // made visible by the barriers of phase_warp
-    }
-    float c2 = 0.f, mu = 0.f;
-    const int i0 = op.omit ? 1 : 0;
-    auto g_at = [&](int r, int c) -> float {  // dL/dIWE at an in-image pixel
-        const float x = img[(int64_t)r * wp.Wp + c];
-        if (!FOLD) return x;
-        const bool in = (r >= i0) && (r < wp.Hp - i0) && (c >= i0) && (c < wp.Wp - i0);
-        return in ? c2 * (x - mu) : 0.f;
-    };
-    unsigned rc[kEPT];
-    float fa[kEPT], fb[kEPT], fdt[kEPT];
-    int fsrc[kEPT];
-    const Window win = phase_warp<MODEL, FRAC, true>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
-    if (FOLD) {  // after the event loads were issued: the statistics loads overlap with them
-        double mud = 0.0;
-        const double coef = chain_coef(op, stat, k, &mud);
-        c2 = (float)(coef * 2.0 / (region_pixels(op.H, op.W, op.omit) - 1.0));
-        mu = (float)mud;
-    }
-#if defined(CMAX_ABL) && CMAX_ABL == 1
-    if (win.h == -12345) gpart[0] = fa[0] + fb[1] + (float)rc[2] + fdt[3] + fsrc[4] + c2 + mu;
-    return;
-#endif
-    const int lane = threadIdx.x & (kWave - 1);
-    if (win.w > 32) {  // a wave per window row: coalesced, no integer division
-        for (int r = threadIdx.x / kWave; r < win.h; r += 4)
-            for (int c = lane; c < win.w; c += kWave) s_win[(r << win.sh) + c] = g_at(win.r0 + r, win.c0 + c);
-    } else {  // narrow window: two rows per wave
-        const int half = lane >> 5, c = lane & 31;
-        for (int r = 2 * (threadIdx.x / kWave) + half; r < win.h; r += 8)
-            if (c < win.w) s_win[(r << win.sh) + c] = g_at(win.r0 + r, win.c0 + c);
-    }
-    if (threadIdx.x < kWave) s_win[kDummy + threadIdx.x] = 0.f;  // masked corners read 0 from here
-    __syncthreads();
-#if defined(CMAX_ABL) && CMAX_ABL == 2
-    if (s_win[threadIdx.x] == -12345.f) gpart[0] = fa[0] + fb[1] + (float)rc[2] + fdt[3] + fsrc[4];
-    return;
-#endif
-    const int hw = wp.H * wp.W;
-    const int dummy = kDummy + lane;
-    const int stride = 1 << win.sh;
-    float accx = 0.f, accy = 0.f;
-#pragma unroll
-    for (int j = 0; j < kEPT; ++j) {
-        const int row = (int)(rc[j] >> 16) - 16384, col = (int)(rc[j] & 0xFFFFu) - 16384;  // empty slot: far outside
-        const int lr = row - win.r0, lc = col - win.c0;
-        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
-        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
-        const int base = (lr << win.sh) + lc;
-        // g[0] = G00 (row, col), g[1] = G10 (row+1, col), g[2] = G01 (row, col+1), g[3] = G11; a corner
-        // outside the window reads the zero scratch word (outside the image: masked vote, zero gradient)
-        float g[4];
-        g[0] = s_win[(r_in0 && c_in0) ? base : dummy];
-        g[1] = s_win[(r_in1 && c_in0) ? base + stride : dummy];
-        g[2] = s_win[(r_in0 && c_in1) ? base + 1 : dummy];
-        g[3] = s_win[(r_in1 && c_in1) ? base + stride + 1 : dummy];
-        if (win.clipped && rc[j] != 0u) {  // workgroup-uniform, rare: corners outside the window but inside the image
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = row + (q & 1), c = col + (q >> 1);
-                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
-                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) g[q] = g_at(r, c);
-            }
-        }
-        const bool valid = rc[j] != 0u;
-        const float a = fa[j], b = fb[j];
-        const float dt = valid ? fdt[j] : 0.f;
-        const float gx = (1.f - b) * (g[1] - g[0]) + b * (g[3] - g[2]);
-        const float gy = (1.f - a) * (g[2] - g[0]) + a * (g[3] - g[1]);
-        const unsigned key = valid ? (unsigned)fsrc[j] : 0xFF000000u + (unsigned)lane * 0x1001u;  // invalid: (row, col) = (lane, lane), bin 255 -- never equal to a neighbour
-        if (MODEL == CMAX_MODEL_2DOF) {
-            accx = fmaf(dt, gx, accx);  // <= kEPT terms in fp32, then fp64 across the workgroup
-            accy = fmaf(dt, gy, accy);
-        } else {
-            // segmented inclusive scan over the wave: lanes hold consecutive sorted events, a run =
-            // adjacent lanes with the same key (voxel keys of one pixel interleave time bins, so the
-            // scan carries head flags instead of comparing keys at a distance)
-            float vx = -dt * gx, vy = -dt * gy;
-            const unsigned kprev = (unsigned)dpp_i<kDppWaveShr1>((int)~key, (int)key);  // lane 0 sees ~key: always a head
-            const int head = (kprev != key || !valid) ? 1 : 0;
-            const int hnext = dpp_i<kDppWaveShl1>(1, head);  // lane 63 sees 1: always a tail
-            const int tail = hnext != 0;
-            seg_scan64(head, vx, vy, lane);
-            if (valid && tail) {  // last lane of its run holds the run's sum
-                // cell of the run in the workgroup's accumulator: [bin][tile - tile0][pixel in tile]
-                const int ix = (int)(key & 0xFFFu), iy = (int)((key >> 12) & 0xFFFu), bin = (int)(key >> 24);
-                const int tl = ((ix >> 4) * wp.ntc + (iy >> 4)) - sg.z;
-                const int cell = ((bin * sg.w + tl) << 8) + ((ix & 15) << 4) + (iy & 15);
-                if (kLdsAcc && (unsigned)cell < (unsigned)kAccCells) {
-                    atomic_add(&s_acc[cell], vx);  // ds_add_f32: slow per op, but only one per run
-                    atomic_add(&s_acc[kAccCells + cell], vy);
-                } else {  // accumulator too small for this segment (very many time bins): straight to memory
-                    const int64_t g = (int64_t)bin * 2 * hw + (int64_t)ix * wp.W + iy;
-                    atomic_add(&gflow[g], vx);
-                    atomic_add(&gflow[g + hw], vy);
-                }
-            }
-        }
-    }
-    if (kLdsAcc) {
-        // flush: 64 lanes = 4 rows x 16 pixels of one source tile -> one global atomic per non-zero cell
-        __syncthreads();
-        const int nbin = MODEL == CMAX_MODEL_VOXEL ? wp.T : 1;
-        int ncell = (nbin * sg.w) << 8;
-        if (ncell > kAccCells) ncell = kAccCells;
-        for (int cell = threadIdx.x; cell < ncell; cell += 256) {
-            const float vx = s_acc[cell], vy = s_acc[kAccCells + cell];
-            if (vx == 0.f && vy == 0.f) continue;
-            const int bt = cell >> 8, bin = bt / sg.w, tile = sg.z + (bt - bin * sg.w);
-            const int ix = ((tile / wp.ntc) << 4) + ((cell >> 4) & 15), iy = ((tile % wp.ntc) << 4) + (cell & 15);
-            const int64_t g = (int64_t)bin * 2 * hw + (int64_t)ix * wp.W + iy;
-            atomic_add(&gflow[g], vx);
-            atomic_add(&gflow[g + hw], vy);
-        }
-    }
-    if (MODEL == CMAX_MODEL_2DOF) {
-        double acc[2] = {(double)accx, (double)accy};
-        block_sum<2>(acc, s_red);
-        if (threadIdx.x == 0) {
-            gpart[2 * sidx] = acc[0];
-            gpart[2 * sidx + 1] = acc[1];
-        }
-    }
-    // loss: all statistics are complete (K2 ran); done last, by the workgroup of the last segment
-    if (result && sidx == nseg - 1 && threadIdx.x == 0) write_result(op, stat, result);
-}
-
 // =============================================================================================
 // Exact Hessian-vector product (a18): what torch.autograd.functional.vhp returns for the
 // objective (src/solver/scipy_autograd/torch_wrapper.py:51-73) -- the derivative of the analytic
@@ -895,66 +535,6 @@ __device__ __forceinline__ void tangent_delta(const WarpParams &wp, const TanPar
         const int src = bin * 2 * hw + ix * wp.W + iy;
         da = -dt * tp.u[src];  // x' = x - dt * F[0, ix, iy]
         db = -dt * tp.u[src + hw];
-    }
-}
-
-template <int MODEL, bool FRAC>
-__global__ void __launch_bounds__(256) k_vote_tan(EvView ev, WarpParams wp, TanParams tp, const int4 *__restrict__ segs, int nseg,
-                                                  float *__restrict__ dimg, double *__restrict__ stat_zero) {
-    __shared__ int s_win[kWinCap + kWave];
-    __shared__ int s_box[16];
-    if (stat_zero && blockIdx.x == 0 && threadIdx.x < 2 * 32) stat_zero[threadIdx.x] = 0.0;
-    const int sidx = segment_of_block(nseg);
-    if (sidx >= nseg) return;
-    const int4 sg = segs[sidx];
-    unsigned rc[kEPT];
-    float fa[kEPT], fb[kEPT], fdt[kEPT];
-    int fsrc[kEPT];
-    const Window win = phase_warp<MODEL, FRAC, true>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
-    float u0 = 0.f, u1 = 0.f;
-    if (MODEL == CMAX_MODEL_2DOF) {
-        u0 = tp.u[0];
-        u1 = tp.u[1];
-    }
-    const int wn = win.h << win.sh;
-    for (int i = threadIdx.x; i < wn; i += 256) s_win[i] = 0;
-    __syncthreads();
-    const int dummy = kDummy + (int)(threadIdx.x & (kWave - 1));
-#pragma unroll
-    for (int u = 0; u < kEPT; ++u) {
-        const bool valid = rc[u] != 0u;
-        const int row = (int)(rc[u] >> 16) - 16384, col = (int)(rc[u] & 0xFFFFu) - 16384;
-        const float a = fa[u], b = fb[u], na = 1.f - a, nb = 1.f - b;
-        float da = 0.f, db = 0.f;
-        if (valid) tangent_delta<MODEL>(wp, tp, fdt[u], (unsigned)fsrc[u], u0, u1, da, db);
-        // derivatives of w00 = na nb, w10 = a nb, w01 = na b, w11 = a b along (da, db)
-        const float d00 = -nb * da - na * db, d10 = nb * da - a * db, d01 = -b * da + na * db, d11 = b * da + a * db;
-        const int lr = row - win.r0, lc = col - win.c0;
-        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
-        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
-        const int base = (lr << win.sh) + lc, stride = 1 << win.sh;
-        atomicAdd(&s_win[(r_in0 && c_in0) ? base : dummy], (r_in0 && c_in0) ? __float2int_rn(d00 * tp.fix) : 0);
-        atomicAdd(&s_win[(r_in1 && c_in0) ? base + stride : dummy], (r_in1 && c_in0) ? __float2int_rn(d10 * tp.fix) : 0);
-        atomicAdd(&s_win[(r_in0 && c_in1) ? base + 1 : dummy], (r_in0 && c_in1) ? __float2int_rn(d01 * tp.fix) : 0);
-        atomicAdd(&s_win[(r_in1 && c_in1) ? base + stride + 1 : dummy], (r_in1 && c_in1) ? __float2int_rn(d11 * tp.fix) : 0);
-        if (win.clipped && valid) {
-            const float dv[4] = {d00, d10, d01, d11};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = row + (q & 1), c = col + (q >> 1);
-                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
-                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) atomic_add(&dimg[(int64_t)r * wp.Wp + c], dv[q]);
-            }
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    for (int r = wave; r < win.h; r += 4) {
-        float *dst = dimg + (int64_t)(win.r0 + r) * wp.Wp + win.c0;
-        for (int c = lane; c < win.w; c += kWave) {
-            const int v = s_win[(r << win.sh) + c];
-            if (v != 0) atomic_add(&dst[c], (float)v * tp.inv_fix);
-        }
     }
 }
 
@@ -1032,91 +612,20 @@ k_gimage_tan(const float *__restrict__ img, const float *__restrict__ dimg, ObjP
     }
 }
 
-// T3: per-event second-order gather.  G = dL/dIWE (current), Gp = its tangent.
-template <int MODEL, bool FRAC>
-__global__ void __launch_bounds__(256)
-k_grad_hvp(EvView ev, WarpParams wp, TanParams tp, const int4 *__restrict__ segs, int nseg, const float *__restrict__ G,
-           const float *__restrict__ Gp, double *__restrict__ gpart, float *__restrict__ hflow) {
-    __shared__ float s_g[kWinCap + kWave];
-    __shared__ float s_p[kWinCap + kWave];
-    __shared__ int s_box[16];
-    __shared__ double s_red[2 * 4];
-    const int sidx = segment_of_block(nseg);
-    if (sidx >= nseg) return;
-    const int4 sg = segs[sidx];
-    unsigned rc[kEPT];
-    float fa[kEPT], fb[kEPT], fdt[kEPT];
-    int fsrc[kEPT];
-    const Window win = phase_warp<MODEL, FRAC, true>(ev, wp, sg, rc, fa, fb, fdt, fsrc, s_box);
-    float u0 = 0.f, u1 = 0.f;
-    if (MODEL == CMAX_MODEL_2DOF) {
-        u0 = tp.u[0];
-        u1 = tp.u[1];
-    }
-    const int lane = threadIdx.x & (kWave - 1);
-    for (int r = threadIdx.x / kWave; r < win.h; r += 4)
-        for (int c = lane; c < win.w; c += kWave) {
-            const int64_t q = (int64_t)(win.r0 + r) * wp.Wp + win.c0 + c;
-            s_g[(r << win.sh) + c] = G[q];
-            s_p[(r << win.sh) + c] = Gp[q];
-        }
-    if (threadIdx.x < kWave) {
-        s_g[kDummy + threadIdx.x] = 0.f;
-        s_p[kDummy + threadIdx.x] = 0.f;
-    }
-    __syncthreads();
-    const int hw = wp.H * wp.W;
-    const int dummy = kDummy + lane, stride = 1 << win.sh;
-    float accx = 0.f, accy = 0.f;
-#pragma unroll
-    for (int j = 0; j < kEPT; ++j) {
-        const bool valid = rc[j] != 0u;
-        const int row = (int)(rc[j] >> 16) - 16384, col = (int)(rc[j] & 0xFFFFu) - 16384;
-        const int lr = row - win.r0, lc = col - win.c0;
-        const bool r_in0 = (unsigned)lr < (unsigned)win.h, r_in1 = (unsigned)(lr + 1) < (unsigned)win.h;
-        const bool c_in0 = (unsigned)lc < (unsigned)win.w, c_in1 = (unsigned)(lc + 1) < (unsigned)win.w;
-        const int base = (lr << win.sh) + lc;
-        const int i00 = (r_in0 && c_in0) ? base : dummy, i10 = (r_in1 && c_in0) ? base + stride : dummy;
-        const int i01 = (r_in0 && c_in1) ? base + 1 : dummy, i11 = (r_in1 && c_in1) ? base + stride + 1 : dummy;
-        float g[4] = {s_g[i00], s_g[i10], s_g[i01], s_g[i11]};
-        float q[4] = {s_p[i00], s_p[i10], s_p[i01], s_p[i11]};
-        if (win.clipped && valid) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = row + (t & 1), c = col + (t >> 1);
-                const bool in_win = (unsigned)(r - win.r0) < (unsigned)win.h && (unsigned)(c - win.c0) < (unsigned)win.w;
-                if (!in_win && (unsigned)r < (unsigned)wp.Hp && (unsigned)c < (unsigned)wp.Wp) {
-                    g[t] = G[(int64_t)r * wp.Wp + c];
-                    q[t] = Gp[(int64_t)r * wp.Wp + c];
-                }
-            }
-        }
-        const float a = fa[j], b = fb[j], dt = fdt[j];
-        float da = 0.f, db = 0.f;
-        if (valid) tangent_delta<MODEL>(wp, tp, dt, (unsigned)fsrc[j], u0, u1, da, db);
-        const float mixed = (g[3] - g[2]) - (g[1] - g[0]);  // d gx / d b = d gy / d a
-        const float hx = mixed * db + (1.f - b) * (q[1] - q[0]) + b * (q[3] - q[2]);
-        const float hy = mixed * da + (1.f - a) * (q[2] - q[0]) + a * (q[3] - q[1]);
-        if (MODEL == CMAX_MODEL_2DOF) {
-            accx = fmaf(dt, hx, accx);
-            accy = fmaf(dt, hy, accy);
-        } else if (valid) {
-            const unsigned key = (unsigned)fsrc[j];
-            const int ix = (int)(key & 0xFFFu), iy = (int)((key >> 12) & 0xFFFu), bin = (int)(key >> 24);
-            const int64_t o = (int64_t)bin * 2 * hw + (int64_t)ix * wp.W + iy;
-            atomic_add(&hflow[o], -dt * hx);  // the HVP runs once per CG step: plain per-event atomics are enough
-            atomic_add(&hflow[o + hw], -dt * hy);
-        }
-    }
-    if (MODEL == CMAX_MODEL_2DOF) {
-        double acc[2] = {(double)accx, (double)accy};
-        block_sum<2>(acc, s_red);
-        if (threadIdx.x == 0) {
-            gpart[2 * sidx] = acc[0];
-            gpart[2 * sidx + 1] = acc[1];
-        }
-    }
-}
+}  // namespace cmax
+
+// the event kernels, once per workgroup size
+namespace cmax {
+#define CMAX_THREADS 256
+#define CMAX_EVENT_NS t256
+#include "cmax_event_kernels.inc"
+#undef CMAX_THREADS
+#undef CMAX_EVENT_NS
+#define CMAX_THREADS 512
+#define CMAX_EVENT_NS t512
+#include "cmax_event_kernels.inc"
+#undef CMAX_THREADS
+#undef CMAX_EVENT_NS
 
 // 2-DoF only: gradient = sum of the per-segment partials of every K3 launch (one workgroup).
 __global__ void __launch_bounds__(256)
@@ -1151,14 +660,25 @@ static float ref_fraction(int ref_mode, double frac) {
     return (float)frac;
 }
 
+// 512-thread workgroups (4 events per thread) once the work list exceeds what the chip holds at once
+static bool wide_groups(const cmax_handle_s *h) { return h->nseg > 1024; }
+
 template <int MODEL>
 static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, float *img, double *stat_zero, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfVote, s);
+#define CMAX_LAUNCH_VOTE(NS, FRAC) \
+    hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero)
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (h->has_frac) hipLaunchKernelGGL((k_vote<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
-        else hipLaunchKernelGGL((k_vote<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero);
+        if (wide_groups(h)) {
+            if (h->has_frac) CMAX_LAUNCH_VOTE(t512, true);
+            else CMAX_LAUNCH_VOTE(t512, false);
+        } else {
+            if (h->has_frac) CMAX_LAUNCH_VOTE(t256, true);
+            else CMAX_LAUNCH_VOTE(t256, false);
+        }
     }
+#undef CMAX_LAUNCH_VOTE
 }
 
 template <int MODEL>
@@ -1166,17 +686,24 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
                         const ObjParams &op, int k, double *gpart, float *gflow, double *result, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfGrad, s);
-#define CMAX_LAUNCH_GRAD(FRAC, FOLD) \
-    hipLaunchKernelGGL((k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(256), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result)
+#define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD) \
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result)
+#define CMAX_LAUNCH_GRAD_NS(NS)                    \
+    if (h->has_frac) {                             \
+        if (fold) CMAX_LAUNCH_GRAD(NS, true, true); \
+        else CMAX_LAUNCH_GRAD(NS, true, false);    \
+    } else {                                       \
+        if (fold) CMAX_LAUNCH_GRAD(NS, false, true); \
+        else CMAX_LAUNCH_GRAD(NS, false, false);   \
+    }
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (h->has_frac) {
-            if (fold) CMAX_LAUNCH_GRAD(true, true);
-            else CMAX_LAUNCH_GRAD(true, false);
+        if (wide_groups(h)) {
+            CMAX_LAUNCH_GRAD_NS(t512)
         } else {
-            if (fold) CMAX_LAUNCH_GRAD(false, true);
-            else CMAX_LAUNCH_GRAD(false, false);
+            CMAX_LAUNCH_GRAD_NS(t256)
         }
     }
+#undef CMAX_LAUNCH_GRAD_NS
 #undef CMAX_LAUNCH_GRAD
 }
 
@@ -1675,16 +1202,16 @@ namespace cmax {
 template <int MODEL>
 static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, float *draw, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
-    if (h->has_frac) hipLaunchKernelGGL((k_vote_tan<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
-    else hipLaunchKernelGGL((k_vote_tan<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+    if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+    else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
 }
 
 template <int MODEL>
 static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, const float *G,
                             const float *Gp, double *gpart, float *hflow, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
-    if (h->has_frac) hipLaunchKernelGGL((k_grad_hvp<MODEL, true>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
-    else hipLaunchKernelGGL((k_grad_hvp<MODEL, false>), dim3(grid), dim3(256), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
 }
 
 }  // namespace cmax
