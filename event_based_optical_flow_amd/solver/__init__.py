@@ -3,5 +3,9 @@ patch-based flow.  The pyramid driver, Optuna initialisers and metrics of the re
 classes are outside the hot path."""
 from . import scipy_autograd
 from .patch_objective import PatchFlowObjective, patch_pad
+from .pyramid import PyramidalPatchContrastMaximization
 
-__all__ = ["scipy_autograd", "PatchFlowObjective", "patch_pad"]
+# registry name of the reference (src/solver/__init__.py:14-19)
+collections = {"pyramidal_patch_contrast_maximization": PyramidalPatchContrastMaximization}
+
+__all__ = ["scipy_autograd", "PatchFlowObjective", "patch_pad", "PyramidalPatchContrastMaximization", "collections"]

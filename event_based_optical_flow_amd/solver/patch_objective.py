@@ -54,16 +54,37 @@ class PatchFlowObjective:
 
     @property
     def has_exact_hvp(self) -> bool:
-        # patch -> dense is linear, so H_x = t^2 P^T H_flow P; the Burgers voxel chain is nonlinear and has no
-        # second-order adjoint yet (TorchWrapper then differences the analytic gradient)
-        return (not self.time_aware) and self.contrast.has_exact_hvp
+        """TorchWrapper calls `hvp` when this is True.  Time-ignorant objectives: exact (patch -> dense is
+        linear, so H_x = t^2 P^T H_flow P).  Time-aware objectives: the Burgers voxel chain is nonlinear
+        and has no second-order adjoint yet, so `hvp` differences the analytic gradient of the SMOOTH part
+        only -- differencing the whole objective would push the kinks of the total-variation term
+        (|.| has a jump in its gradient) into the curvature and stall Newton-CG."""
+        return self.contrast.has_exact_hvp
 
-    def hvp(self, x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-        """Exact Hessian-vector product w.r.t. the patch motion x."""
+    def _smooth_grad(self, x: torch.Tensor) -> torch.Tensor:
+        """Gradient of the contrast terms (everything except total_variation) w.r.t. x."""
+        xt = x.detach().clone().requires_grad_()
+        loss = 0.0
+        for name, weight, desc in self.contrast.terms:
+            if desc is None:
+                continue
+            from ..cmax import _FusedFn
+
+            loss = loss + float(weight) * _FusedFn.apply(self.dense_flow(xt), self.handle, desc)
+        (g,) = torch.autograd.grad(loss, xt)
+        return g
+
+    def hvp(self, x: torch.Tensor, v: torch.Tensor, disp_step: float = 0.05) -> torch.Tensor:
+        """Hessian-vector product w.r.t. the patch motion x (exact unless time-aware, see has_exact_hvp)."""
         if not self.has_exact_hvp:
-            raise NotImplementedError("exact HVP needs a time-ignorant objective")
+            raise NotImplementedError("no HVP for 'inv'-weighted hybrid terms")
         x = x.to(self.handle.device)
         v = v.to(self.handle.device)
+        if self.time_aware:
+            # step measured in PIXELS OF DISPLACEMENT over the batch (x is pixel per time unit): a fixed
+            # 0.05 px keeps the quotient above the fp32 noise of the gradient and below the pixel scale
+            h = disp_step / (self.t_scale * float(v.abs().max()))
+            return (self._smooth_grad(x + h * v) - self._smooth_grad(x - h * v)) / (2.0 * h)
         shape = (2,) + self.patch_image_size
         size, sw, pad = self.handle.image_size, self.sliding_window, self.pad
         dense = F.patch_to_dense(x.detach().reshape(shape), size, sw, pad) * self.t_scale

@@ -1,0 +1,168 @@
+"""Coarse-to-fine patch solver on the GPU objective (SURVEY.md section 8f rank 4 -- a "next" row).
+
+Same constructor signature, config keys, registry name and return value as the reference's
+`PyramidalPatchContrastMaximization` (src/solver/patch_contrast_pyramid.py:31-67, 149-177), so
+`solver.collections["pyramidal_patch_contrast_maximization"](image_shape, calib, solver_cfg,
+optimizer_cfg, output_cfg, None).optimize(events)` works as in `main.py:141-179`.
+
+What is the same: the patch grids per scale (prepare_patch / prepare_pyramidal_patch, lines 69-100),
+the objective per scale (`PatchFlowObjective` == `objective_scipy`, pinned by golden fixtures), the
+SciPy method and options, warm start from the previous frame, fine-to-coarse feedback.
+What differs, and is NOT pinned against the reference (its dependencies are absent from this image and
+its trajectories depend on Optuna's TPE sampler):
+  * per-patch Optuna re-initialisation at finer scales (lines 320-428) is not reproduced -- finer
+    scales start from the expanded coarser solution;
+  * skimage.transform.pyramid_expand / pyramid_reduce (lines 220-222, 265-267) are restated with
+    scipy.ndimage (order-1 zoom + Gaussian sigma = 2*2/6, 'reflect') on the tiny [2,ph,pw] arrays.
+These are host-side operations on a few hundred numbers between scales, not part of the hot path.
+"""
+import logging
+from typing import Dict, Optional
+
+import numpy as np
+import scipy.ndimage as ndi
+
+from ..cmax import CMaxHandle
+from . import scipy_autograd
+from .patch_objective import PatchFlowObjective
+
+logger = logging.getLogger(__name__)
+
+SCIPY_OPTIMIZERS = ["Nelder-Mead", "Powell", "CG", "BFGS", "Newton-CG", "L-BFGS-B", "TNC", "COBYLA", "SLSQP",
+                    "trust-constr", "dogleg", "trust-ncg", "trust-exact", "trust-krylov"]
+
+
+def _check_key_and_bool(config: dict, key: str) -> bool:
+    return key in config.keys() and bool(config[key])
+
+
+def pyramid_expand(motion: np.ndarray) -> np.ndarray:
+    """[2,h,w] -> [2,2h,2w]: order-1 up-sampling then Gaussian smoothing (sigma = 2*upscale/6)."""
+    out = np.stack([ndi.zoom(c, 2, order=1, mode="reflect", grid_mode=True) for c in motion])
+    return np.stack([ndi.gaussian_filter(c, 2 * 2 / 6.0, mode="reflect") for c in out])
+
+
+def pyramid_reduce(motion: np.ndarray) -> np.ndarray:
+    """[2,h,w] -> [2,ceil(h/2),ceil(w/2)]: Gaussian smoothing (sigma = 2*downscale/6) then order-1 down-sampling."""
+    sm = np.stack([ndi.gaussian_filter(c, 2 * 2 / 6.0, mode="reflect") for c in motion])
+    shape = (int(np.ceil(motion.shape[1] / 2)), int(np.ceil(motion.shape[2] / 2)))
+    return np.stack([ndi.zoom(c, (shape[0] / c.shape[0], shape[1] / c.shape[1]), order=1, mode="reflect", grid_mode=True)
+                     for c in sm])
+
+
+class PyramidalPatchContrastMaximization:
+    def __init__(self, image_shape: tuple, calibration_parameter: dict, solver_config: dict = {},
+                 optimizer_config: dict = {}, output_config: dict = {}, visualize_module=None):
+        self.image_shape = tuple(image_shape)
+        self.calib_param = calibration_parameter
+        self.slv_config = solver_config
+        self.opt_config = optimizer_config
+        self.out_config = output_config
+        self.visualizer = visualize_module
+        self.opt_method = optimizer_config["method"]
+        if self.opt_method not in SCIPY_OPTIMIZERS:
+            raise NotImplementedError(f"Optimizer {self.opt_method} is not supported (SciPy methods only)")
+        self.padding = solver_config["outer_padding"] if "outer_padding" in solver_config else 0
+        self.iwe_config = solver_config["iwe"]
+        if self.iwe_config["method"] != "bilinear_vote":
+            raise NotImplementedError("the fused objective accumulates with bilinear_vote")
+        self.motion_model = solver_config["motion_model"]
+        self.motion_vector_size = 2
+        self.cost_name = solver_config["cost"]
+        self.cost_weight = solver_config.get("cost_with_weight") if self.cost_name == "hybrid" else None
+        self.normalize_t_in_batch = True
+        # time-aware set-up (src/solver/base.py:211-228)
+        self.is_time_aware = _check_key_and_bool(solver_config, "time_aware")
+        if self.is_time_aware:
+            self.time_bin = solver_config["time_bin"]
+            self.flow_interpolation = solver_config["flow_interpolation"]
+            self.t0_flow_location = solver_config["t0_flow_location"]
+            if _check_key_and_bool(solver_config, "scale_later"):
+                raise NotImplementedError("scale_later is not built")
+        else:
+            self.time_bin, self.flow_interpolation, self.t0_flow_location = 0, "burgers", "middle"
+        # pyramid (patch_contrast_pyramid.py:50-61)
+        patch = solver_config["patch"]
+        self.filter_type = patch["filter_type"]
+        self.coarest_scale = 1
+        self.patch_scales = patch["scale"]
+        self.cropped_image_shape = (patch["crop_height"], patch["crop_width"])
+        self.patch_shift = ((self.image_shape[0] - self.cropped_image_shape[0]) // 2,
+                            (self.image_shape[1] - self.cropped_image_shape[1]) // 2)
+        self.scaled_patch_size, self.scaled_patch_image_size, self.scaled_n_patch = {}, {}, {}
+        for s in range(self.coarest_scale, self.patch_scales):
+            size = (self.cropped_image_shape[0] // (2 ** s), self.cropped_image_shape[1] // (2 ** s))
+            self.scaled_patch_size[s] = size
+            # patch centres: np.arange(0, image - patch + slide, slide) + patch/2 with slide == patch (lines 87-91)
+            self.scaled_patch_image_size[s] = (len(np.arange(0, self.cropped_image_shape[0], size[0])),
+                                               len(np.arange(0, self.cropped_image_shape[1], size[1])))
+            self.scaled_n_patch[s] = self.scaled_patch_image_size[s][0] * self.scaled_patch_image_size[s][1]
+        self.total_n_patch = sum(self.scaled_n_patch.values())
+        self.previous_frame_best_estimation: Optional[Dict[int, np.ndarray]] = None
+        self.history = []  # (scale, OptimizeResult)
+
+    # -- reference API ---------------------------------------------------------------------------
+    def set_previous_frame_best_estimation(self, previous_best):
+        self.previous_frame_best_estimation = previous_best.copy() if isinstance(previous_best, dict) else np.copy(previous_best)
+
+    def initialize_random(self, n_patch: int) -> np.ndarray:
+        x0 = np.random.rand(self.motion_vector_size, n_patch).astype(np.float64)
+        p = self.opt_config["parameters"]
+        x0[0] = x0[0] * (p["trans_x"]["max"] - p["trans_x"]["min"]) + p["trans_x"]["min"]
+        x0[1] = x0[1] * (p["trans_y"]["max"] - p["trans_y"]["min"]) + p["trans_y"]["min"]
+        return x0
+
+    def optimize(self, events: np.ndarray) -> Dict[int, np.ndarray]:
+        """events [n,4] (x row, y col, t, p) -> {scale: motion [2, ph, pw]} in pixel per time unit."""
+        logger.info(f"DoF is {self.motion_vector_size * self.total_n_patch}")
+        handle = CMaxHandle(self.image_shape, self.padding).set_events(events, time_bin=self.time_bin)
+        t = events[:, 2]
+        t_scale = float(t.max() - t.min()) if self.normalize_t_in_batch else 1.0
+        best: Dict[int, np.ndarray] = {}
+        self.history = []
+        for s in range(self.coarest_scale, self.patch_scales):
+            pis = self.scaled_patch_image_size[s]
+            objective = PatchFlowObjective(
+                handle, t_scale, pis, self.scaled_patch_size[s], self.scaled_patch_size[s], self.patch_shift,
+                cost=self.cost_name, cost_with_weight=self.cost_weight, blur_sigma=self.iwe_config["blur_sigma"],
+                time_aware=self.is_time_aware, time_bin=self.time_bin, flow_interpolation=self.flow_interpolation,
+                t0_flow_location=self.t0_flow_location, filter_type=self.filter_type)
+            if self.previous_frame_best_estimation is not None and s == self.coarest_scale:
+                x0 = np.copy(self.previous_frame_best_estimation[s]).reshape(-1)
+            elif s > self.coarest_scale:
+                x0 = pyramid_expand(best[s - 1])[:, : pis[0], : pis[1]].reshape(-1)
+                if self.previous_frame_best_estimation is not None:
+                    x0 = (x0 + self.previous_frame_best_estimation[s].reshape(-1)) / 2
+            elif self.slv_config["patch"]["initialize"] == "zero":
+                x0 = np.zeros(2 * self.scaled_n_patch[s])
+            else:
+                x0 = self.initialize_random(self.scaled_n_patch[s]).reshape(-1)
+            res = scipy_autograd.minimize(objective, x0, method=self.opt_method, precision="float64",
+                                          torch_device=str(handle.device),
+                                          options={"gtol": 1e-5, "disp": False, "maxiter": self.opt_config["max_iter"]}
+                                          if self.opt_method in ("Newton-CG", "BFGS", "CG", "L-BFGS-B", "trust-ncg", "trust-krylov")
+                                          else {"maxiter": self.opt_config["max_iter"]})
+            logger.info(f"Scale {s}: loss {res.fun}")
+            self.history.append((s, res))
+            best[s] = np.asarray(res.x).reshape((2,) + pis)
+        self._last_handle, self._last_t_scale = handle, t_scale
+        return self.update_coarse_from_fine(best)
+
+    def update_coarse_from_fine(self, motion_per_scale: dict) -> dict:
+        finest, coarsest = max(motion_per_scale), min(motion_per_scale)
+        refined = {finest: motion_per_scale[finest]}
+        for i in range(finest, coarsest, -1):
+            refined[i - 1] = pyramid_reduce(refined[i])
+        return refined
+
+    def motion_to_dense_flow(self, motion_per_scale: dict) -> np.ndarray:
+        """Finest-scale motion -> dense flow [2,H,W] in pixel per time unit (what the reference visualises)."""
+        import torch
+
+        from .. import functional as F
+        from .patch_objective import patch_pad
+
+        s = max(motion_per_scale)
+        ps = self.scaled_patch_size[s]
+        m = torch.as_tensor(motion_per_scale[s], dtype=torch.float64, device="cuda")
+        return F.patch_to_dense(m, self.image_shape, ps, patch_pad(ps, ps, self.patch_shift)).cpu().numpy()

@@ -151,3 +151,50 @@ def test_exact_hvp_through_the_patch_interpolation(golden):
     fd = w.get_hvp(g[k + "__x"], v.cpu().numpy())
     # the quotient still sees a few cell crossings and fp32 gradient noise / step: agreement to a few per cent
     assert np.abs(hv - fd).max() <= 0.1 * np.abs(fd).max(), (np.abs(hv - fd).max(), np.abs(fd).max())
+
+
+@pytest.mark.parametrize("time_aware", [False, True])
+def test_pyramid_solver_end_to_end(time_aware):
+    """solver.collections[...] with the shipped YAML parameters on a synthetic scene: dots moving along
+    a smooth ground-truth flow.  Coarse-to-fine optimisation on the GPU must recover the flow well
+    below the zero-flow error (the reference's own optimiser trajectories are not reproducible here:
+    Optuna / skimage are absent, see solver/pyramid.py)."""
+    from event_based_optical_flow_amd import solver
+
+    H, W = 68, 90
+    rng = np.random.default_rng(11)
+    V = E.utils.generate_smooth_flow((H, W), 7.0, grid=3, seed=12)  # pixel displacement over the batch
+    n, n_dots = 80_000, 500
+    cx, cy = rng.uniform(4, H - 4, n_dots), rng.uniform(4, W - 4, n_dots)
+    dot = rng.integers(0, n_dots, n)
+    tau = np.sort(rng.uniform(0, 1, n))
+    vx = V[0, cx.astype(int), cy.astype(int)][dot]
+    vy = V[1, cx.astype(int), cy.astype(int)][dot]
+    x = np.clip(np.round(cx[dot] + tau * vx + rng.normal(0, 0.4, n)), 0, H - 1)
+    y = np.clip(np.round(cy[dot] + tau * vy + rng.normal(0, 0.4, n)), 0, W - 1)
+    t_scale = 0.05
+    ev = np.stack([x, y, tau * t_scale, rng.integers(0, 2, n).astype(float)], 1)
+    slv_cfg = {"method": "pyramidal_patch_contrast_maximization", "time_aware": time_aware,
+               "patch": {"initialize": "random", "scale": 4, "crop_height": 64, "crop_width": 80, "filter_type": "bilinear"},
+               "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
+               "cost": "hybrid", "outer_padding": 0,
+               "cost_with_weight": {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+               "iwe": {"method": "bilinear_vote", "blur_sigma": 1}}
+    if time_aware:
+        slv_cfg.update({"time_bin": 10, "flow_interpolation": "burgers", "t0_flow_location": "middle"})
+    # random initialisation like the shipped configs (an exactly-zero start puts every integer-pixel event on a
+    # cell border, the one point where a difference-quotient curvature is meaningless)
+    opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
+               "parameters": {"trans_x": {"min": -30, "max": 30}, "trans_y": {"min": -30, "max": 30}}}
+    np.random.seed(46)
+    slv = solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
+    best = slv.optimize(ev)
+    assert sorted(best) == [1, 2, 3] and best[3].shape == (2, 8, 8) and best[1].shape == (2, 2, 2)
+    flow = slv.motion_to_dense_flow(best) * t_scale  # pixel displacement over the batch
+    mask = np.zeros((H, W), bool)
+    mask[x.astype(int), y.astype(int)] = True
+    mask[:4] = mask[-4:] = False
+    mask[:, :8] = mask[:, -8:] = False
+    aee = np.sqrt(((flow - V) ** 2).sum(0))[mask].mean()
+    aee0 = np.sqrt((V ** 2).sum(0))[mask].mean()
+    assert aee < 0.5 * aee0, (aee, aee0)
