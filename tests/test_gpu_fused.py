@@ -320,3 +320,60 @@ def test_wide_workgroup_path_equals_time_sliced_sum(model):
     assert abs(outs[0][0][0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())
     gsum = (outs[0][1].double() + outs[1][1].double()).cpu().numpy()
     assert rel_max(gsum, grad.double().cpu().numpy()) <= 2e-5
+
+
+def test_voxel_many_time_bins_and_rebinning():
+    """T = 20 bins: one 16x16 tile needs 5120 accumulator cells > the 3072 held in LDS, so part of the
+    flow-gradient runs take the direct global-atomic path; and cmax_set_time_bins re-bins a packed batch."""
+    size, n, Tn = (64, 80), 60_000, 20
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=81)
+    voxel = orc.construct_dense_flow_voxel(E.utils.generate_smooth_flow(size, 8, seed=82), Tn, "burgers", "middle")
+    ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=1)
+    h = E.CMaxHandle(size).set_events(ev)  # packed without bins ...
+    h.set_time_bins(Tn)  # ... re-binned afterwards
+    desc = E.make_descriptor("image_variance", "dense-flow-voxel", sigma=1.0, time_bin=Tn)
+    res, grad = h.evaluate(desc, voxel)
+    assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
+    h2 = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
+    res2, grad2 = h2.evaluate(desc, voxel)
+    assert rel_max(grad2.cpu().numpy(), grad.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("direction", ["before", "after", 0.3, "last"])
+def test_reference_time_variants(direction):
+    """Warp.calculate_reftime's other directions (src/warp.py:216-233) through the fused path."""
+    size, n = (48, 64), 40_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=83)
+    flow = E.utils.generate_smooth_flow(size, 6, seed=84)
+    warped, _ = orc.warp_event(ev, flow, "dense-flow", direction, size)
+    iwe_ref = orc.create_iwe(warped, size, sigma=0)
+    h = E.CMaxHandle(size).set_events(ev)
+    iwe = h.iwe(flow, "dense-flow", direction=direction).cpu().numpy()
+    assert rel_max(iwe, iwe_ref) <= TOL
+
+
+def test_unnormalised_time():
+    """normalize_t = False: dt in the events' own time unit (src/warp.py:254-259)."""
+    size, n = (48, 64), 40_000
+    ev = E.utils.generate_events(n, size[0], size[1], 1.0, 3.5, seed=85)  # period 2.5 time units
+    theta = np.array([3.0, -2.0])
+    warped, _ = orc.warp_event(ev, theta, "2d-translation", "middle", size, normalize_t=False)
+    iwe_ref = orc.create_iwe(warped, size, sigma=1)
+    h = E.CMaxHandle(size).set_events(ev)
+    iwe = h.iwe(theta, "2d-translation", direction="middle", normalize_t=False, sigma=1.0).cpu().numpy()
+    assert rel_max(iwe, iwe_ref) <= TOL
+
+
+def test_dense_with_padding_and_fractional_sources():
+    size, pad, n = (40, 56), 5, 30_000
+    rng = np.random.default_rng(86)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=86)
+    ev[:, 0] = np.clip(ev[:, 0] + rng.uniform(0, 0.99, n), 0, size[0] - 1e-3)
+    ev[:, 1] = np.clip(ev[:, 1] + rng.uniform(0, 0.99, n), 0, size[1] - 1e-3)
+    flow = E.utils.generate_smooth_flow(size, 12, seed=87)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="gradient_magnitude", sigma=1, outer_padding=pad)
+    loss, grads, h = fused_eval(size, ev, flow, "dense-flow", "gradient_magnitude", 1, pad=pad)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
