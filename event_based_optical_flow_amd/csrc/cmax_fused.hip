@@ -11,9 +11,20 @@
 //                   window as 12.20 fixed point with ds_add_u32 (fp32 LDS atomics run at 1/12 of the
 //                   integer rate on gfx950, profiles/r01_microbench.txt), one coalesced global
 //                   atomicAdd per touched window pixel
-//   K2  k_stats     IWE (blurred if sigma>0) -> fp64 sums of the contrast function
-//   K2b k_gimage    G = dL/dIWE (chain factor from the device-side stats), blur transpose
+//   K2  k_stats     IWE (blurred if sigma>0) -> fp64 sums of the contrast function, added to one of
+//                   `nsub` sub-accumulators per image (same-address fp64 atomics serialise at ~12 ns);
+//                   also clears the OTHER vote buffer for the next evaluation (double buffering,
+//                   so the steady state has no memset)
+//   K2b k_gimage    only when sigma>0 or the cost is gradient-based: G = dL/dIWE (chain factor from
+//                   the device-side stats), blur transpose.  Plain variance skips it: K3 forms
+//                   G = coef * (IWE - mean) on the fly
 //   K3  k_grad      per event: re-warp, gather G at the 4 corners -> dL/d(x',y') -> motion gradient
+//                   (2-DoF: per-segment fp64 partials; dense: segmented scan + one atomic per run;
+//                   voxel: LDS accumulators per source tile)
+//   k_finish        sums the per-segment partials, writes loss + gradient, re-zeroes what K1 of the
+//                   next evaluation expects to be zero
+// The event kernels live in cmax_event_kernels.inc, compiled for 256- and 512-thread workgroups
+// (namespaces t256 / t512); the host picks 512 when there are more than 1024 segments.
 //
 // fp32 per event with the integer source pixel split from the fp32 displacement (keeps the
 // bilinear fractions accurate to ulp(displacement) instead of ulp(coordinate)); fp64 reductions.
@@ -80,7 +91,7 @@ struct cmax_handle_s {
     const float *last_iwe[4] = {nullptr, nullptr, nullptr, nullptr};
     // device scalars
     double *d_tmm = nullptr;  // [2]
-    double *d_stat = nullptr;   // [5 slots][8 sub-accumulators][2] contrast statistics (slot 4 = un-warped image)
+    double *d_stat = nullptr;   // [5 slots][32 sub-accumulators][2] contrast statistics (slot 4 = un-warped image)
     // the handle's own vote images are double-buffered: k_stats of evaluation e zeroes the images of
     // evaluation e+1, so the steady state needs no memset node.  zero_mask[b] bit k: image k of buffer b is zero
     int cur_buf = 0;
@@ -260,12 +271,16 @@ struct Warped {
 
 // MODEL: -1 none (orig_iwe), 0 2-DoF, 1 dense, 2 voxel
 template <int MODEL, bool FRAC>
-__device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i, const WarpParams &wp, float tscale, float th0, float th1) {
+__device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i, bool valid, const WarpParams &wp, float tscale, float th0, float th1) {
     Warped w;
     const uint32_t pk = e.x;
     const int ix = (int)(pk & 0xFFFu), iy = (int)((pk >> 12) & 0xFFFu);
     w.dt = (__uint_as_float(e.y) - wp.d) * tscale;  // calculate_dt, src/warp.py:254-259
-    float dx = FRAC ? ev.rx[i] : 0.f, dy = FRAC ? ev.ry[i] : 0.f;
+    float dx = 0.f, dy = 0.f;
+    if (FRAC && valid) {  // `valid` false: an empty slot of the caller (zero event), i may be outside the arrays
+        dx = ev.rx[i];
+        dy = ev.ry[i];
+    }
     w.src = ix * wp.W + iy;
     if (MODEL == CMAX_MODEL_2DOF) {
         dx = fmaf(w.dt, th0, dx);  // x' = x + dt*theta0, src/warp.py:506-515
@@ -304,7 +319,24 @@ struct Window {
     int sh;            // LDS row stride = 1 << sh (power of two: a shift instead of an integer multiply per vote)
     bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
 };
-constexpr int kDummy = kWinCap;
+constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
+constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
+                                    // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
+static_assert(kScratch >= 64 + kWinMaxW + 2, "scratch must hold a per-lane 2x2 footprint at the widest stride");
+
+// v_cvt_rpi_i32_f32: floor(x + 0.5) in one instruction (rndne + cvt are two)
+__device__ __forceinline__ int cvt_rpi(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+typedef unsigned short ushort2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {  // v_pk_min_u16: both 16-bit halves at once
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(ushort2_v, a), __builtin_bit_cast(ushort2_v, b)));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2_v, a), __builtin_bit_cast(ushort2_v, b)));
+}
 
 // ---- wave64 segmented inclusive scan without LDS traffic -------------------------------------------
 // ds_bpermute-based __shfl_up costs ~16 cycles per wave instruction on gfx950 and the 6-step scan of
@@ -319,7 +351,7 @@ __device__ __forceinline__ int dpp_i(int old, int v) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
 }
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
-constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 
 // head: 1 on the first lane of every run.  On return (vx, vy) of the LAST lane of a run hold the run's sums.
 __device__ __forceinline__ void seg_scan64(int head, float &vx, float &vy, int lane) {
@@ -935,13 +967,18 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     h->n = n - flags[1];
     h->tmin_host = tmm_host[0];
     h->tmax_host = tmm_host[1];
-    // Segments: consecutive tiles of one tile row are merged while they fit (sparse batches), a dense
-    // tile is split into several segments; never more than kSegMax events (fixed-point range).
-    // max tiles per segment: the flow-gradient accumulator of the dense / voxel K3 holds
-    // kAccCells cells = tiles * 256 pixels * time bins
+    // Segments = the work items of the event kernels: <= kSegMax consecutive sorted events (fixed-point range)
+    // inside one tile row, spanning <= max_tiles source tiles (the flow-gradient accumulator of the voxel K3
+    // holds kAccCells cells = tiles * 256 pixels * time bins).  Two regimes, measured on MI355X:
+    //   * batches that fill the chip several times over (> 1024 full segments): cut every kSegMax events, tile
+    //     boundaries ignored -- every workgroup full (dense K3 of cfg3 30 -> 25 us);
+    //   * smaller batches are latency-bound: small tiles are merged while they fit, a tile with more than
+    //     kSegMax events is split into EQUAL parts -- tile-aligned windows are tighter and no workgroup is left
+    //     with a small remainder (cfg2: 2040 + 806 per tile -> 2 x 1423).
     const int bins = n_time_bin > 0 ? n_time_bin : 1;
     int max_tiles = kAccCells / (256 * bins);
     if (max_tiles < 1) max_tiles = 1;
+    const bool free_cut = h->n > (int64_t)1024 * kSegMax;
     std::vector<int4> segs;
     int begin = 0, count = 0, row_of_begin = -1, tile0 = 0, tile_last = 0;
     auto close = [&]() {
@@ -952,7 +989,12 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         int b = tile_start[t], c = tile_start[t + 1] - tile_start[t];
         const int trow = t / h->ntc;
         if (c == 0) continue;
-        if (count > 0 && (trow != row_of_begin || count + c > kSegMax || t - tile0 + 1 > max_tiles)) close();
+        if (count > 0 && (trow != row_of_begin || t - tile0 + 1 > max_tiles || (!free_cut && count + c > kSegMax))) close();
+        int limit = kSegMax;
+        if (!free_cut && c > kSegMax) {
+            const int parts = (c + kSegMax - 1) / kSegMax;
+            limit = (c + parts - 1) / parts;
+        }
         while (c > 0) {
             if (count == 0) {
                 begin = b;
@@ -960,11 +1002,11 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
                 tile0 = t;
             }
             tile_last = t;
-            const int take = c < kSegMax - count ? c : kSegMax - count;
+            const int take = c < limit - count ? c : limit - count;
             count += take;
             b += take;
             c -= take;
-            if (count == kSegMax) close();
+            if (count >= limit) close();
         }
     }
     close();
