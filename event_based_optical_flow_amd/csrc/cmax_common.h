@@ -44,10 +44,21 @@ static inline int stream_grid(int64_t n, int block) {
 }
 
 // ---- wave / block reductions (64-wide) -------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+// DPP on the VALU instead of ds_bpermute shuffles (~16 cycles each on gfx950): 4 row shifts, then lane 15 of
+// each row into the next row and lane 31 into rows 2-3; the sum of the wave ends up in LANE 63 only.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double v) {  // lanes without a source read 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v += dpp_shift<0x111>(v);  // row_shr:1
+    v += dpp_shift<0x112>(v);  // row_shr:2
+    v += dpp_shift<0x114>(v);  // row_shr:4
+    v += dpp_shift<0x118>(v);  // row_shr:8
+    v += dpp_shift<0x142>(v);  // row_bcast:15
+    v += dpp_shift<0x143>(v);  // row_bcast:31
     return v;
 }
 
@@ -56,17 +67,18 @@ template <int K>
 __device__ __forceinline__ void block_sum(double (&v)[K], double *smem) {
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
-    if (lane == 0) {
+    for (int k = 0; k < K; ++k) v[k] = wave_sum_lane63(v[k]);
+    if (lane == kWave - 1) {
 #pragma unroll
         for (int k = 0; k < K; ++k) smem[k * nw + wid] = v[k];
     }
     __syncthreads();
-    if (wid == 0) {
+    if (threadIdx.x == 0) {  // <= 16 waves: a serial sum beats a second cross-lane phase
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            double x = lane < nw ? smem[k * nw + lane] : 0.0;
-            v[k] = wave_sum(x);
+            double x = 0.0;
+            for (int w = 0; w < nw; ++w) x += smem[k * nw + w];
+            v[k] = x;
         }
     }
     __syncthreads();

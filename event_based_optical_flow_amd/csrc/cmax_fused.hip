@@ -96,7 +96,7 @@ struct cmax_handle_s {
     // evaluation e+1, so the steady state needs no memset node.  zero_mask[b] bit k: image k of buffer b is zero
     int cur_buf = 0;
     unsigned zero_mask[2] = {0u, 0u};
-    double *d_gpart = nullptr;  // [4 reference times][nseg][2] per-segment 2-DoF gradient partials
+    double *d_gpart = nullptr;  // [4 reference times][nseg][2 (or 6: deferred statistics)] per-segment 2-DoF partials
     // orig-IWE cache key
     bool orig_valid = false;
     double orig_sigma = -1;
@@ -319,6 +319,10 @@ struct Window {
     int sh;            // LDS row stride = 1 << sh (power of two: a shift instead of an integer multiply per vote)
     bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
 };
+// how K3 obtains dL/dIWE: from a materialised G image; folded G = c2 (IWE - mu) with the statistics K2 left in
+// `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
+// applied by k_finish_deferred, and K2 is not launched at all
+constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2;
 constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
@@ -675,6 +679,55 @@ k_finish(const double *__restrict__ gpart, int n_gpart, double *__restrict__ gth
     }
 }
 
+// 2-DoF, plain variance, deferred statistics: K3 left per segment (S1x, S1y, S2x, S2y, sum I, sum I^2) with
+//   S1 = sum_e dt * bilinear-difference(1_Omega I),  S2 = the same of 1_Omega.  With G = c (I - mu) 1_Omega,
+//   c = 2 coef / (n - 1):  dL/dtheta = sum_k c_k (S1_k - mu_k S2_k);  loss and coef_k from the image sums.
+__global__ void __launch_bounds__(256)
+k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *__restrict__ gpart, int nseg,
+                  double *__restrict__ result, double *__restrict__ gtheta) {
+    __shared__ double s_red[6 * 4];
+    __shared__ double s_sum[4][6];
+    for (int k = 0; k < op.n_ref; ++k) {
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const double *gp = gpart + (int64_t)k * nseg * 6;
+        for (int i = threadIdx.x; i < nseg; i += blockDim.x) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[q] += gp[6 * i + q];
+        }
+        block_sum<6>(acc, s_red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s_sum[k][q] = acc[q];
+        }
+    }
+    if (threadIdx.x != 0) return;
+    const double npix = region_pixels(op.H, op.W, op.omit);
+    const double v_orig = op.normalized ? orig_value(op, stat) : 0.0;
+    double loss = 0.0, g0 = 0.0, g1 = 0.0;
+    for (int k = 0; k < op.n_ref; ++k) {
+        const double *S = s_sum[k];
+        const double mu = S[4] / npix;
+        const double v = (S[5] - S[4] * mu) / (npix - 1.0);  // unbiased like torch.var, image_variance.py:55
+        result[1 + k] = v;
+        double coef;
+        if (!op.normalized) {
+            loss += op.mult[k] * (op.minimize ? -v : v);
+            coef = op.mult[k] * (op.minimize ? -1.0 : 1.0);
+        } else {
+            loss += op.mult[k] * (op.minimize ? v_orig / v : v / v_orig);
+            coef = op.mult[k] * (op.minimize ? -v_orig / (v * v) : 1.0 / v_orig);
+        }
+        if (op.negate) coef = -coef;
+        const double c = coef * 2.0 / (npix - 1.0);
+        g0 += c * (S[0] - mu * S[2]);
+        g1 += c * (S[1] - mu * S[3]);
+    }
+    result[0] = op.negate ? -loss : loss;
+    result[5] = v_orig;
+    gtheta[0] = g0;
+    gtheta[1] = g1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side orchestration
 // ---------------------------------------------------------------------------------------------
@@ -714,19 +767,22 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 }
 
 template <int MODEL>
-static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const float *img, bool fold,
-                        const ObjParams &op, int k, double *gpart, float *gflow, double *result, hipStream_t s) {
+static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const float *img, int fold,
+                        const ObjParams &op, int k, double *gpart, float *gflow, double *result, float *zero_img, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfGrad, s);
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result)
-#define CMAX_LAUNCH_GRAD_NS(NS)                    \
-    if (h->has_frac) {                             \
-        if (fold) CMAX_LAUNCH_GRAD(NS, true, true); \
-        else CMAX_LAUNCH_GRAD(NS, true, false);    \
-    } else {                                       \
-        if (fold) CMAX_LAUNCH_GRAD(NS, false, true); \
-        else CMAX_LAUNCH_GRAD(NS, false, false);   \
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result, zero_img)
+#define CMAX_LAUNCH_GRAD_FR(NS, FRAC)                                                  \
+    if (fold == kFoldDeferred) {                                                       \
+        if constexpr (MODEL == CMAX_MODEL_2DOF) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); \
+    } else if (fold == kFoldStats) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);             \
+    else CMAX_LAUNCH_GRAD(NS, FRAC, kFoldNone);
+#define CMAX_LAUNCH_GRAD_NS(NS)          \
+    if (h->has_frac) {                   \
+        CMAX_LAUNCH_GRAD_FR(NS, true)    \
+    } else {                             \
+        CMAX_LAUNCH_GRAD_FR(NS, false)   \
     }
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
         if (wide_groups(h)) {
@@ -736,6 +792,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
         }
     }
 #undef CMAX_LAUNCH_GRAD_NS
+#undef CMAX_LAUNCH_GRAD_FR
 #undef CMAX_LAUNCH_GRAD
 }
 
@@ -1015,7 +1072,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         dev_free(&h->d_segs);
         dev_free(&h->d_gpart);
         int rc = dev_alloc(h, &h->d_segs, h->nseg);
-        if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 2);
+        if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 6);
         if (rc) return rc;
         h->seg_cap = h->nseg;
     }
@@ -1135,12 +1192,18 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         }
     }
 
+    // 2-DoF + plain variance with a gradient: K3 gathers the image statistics itself and k_finish_deferred applies
+    // the chain factors -- no K2 launch (unless a workgroup's slice of the image would get long)
+    const bool two_dof = d->model == CMAX_MODEL_2DOF;
+    const bool fold_var = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
+    const bool deferred = grad && two_dof && fold_var && h->n > 0 && npix <= (int64_t)h->nseg * 8192;
     // contrast statistics per reference time
     for (int k = 0; k < d->n_ref; ++k) {
         const float *img = nullptr;
         rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
         if (rc) return rc;
         h->last_iwe[k] = img;
+        if (deferred) continue;
         rc = launch_stats(h, d->cost, img, d->omit_boundary, k, zero_next ? zero_next + k * npix : nullptr, s);
         if (rc) return rc;
     }
@@ -1150,7 +1213,6 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
     if (!grad) return 0;
 
-    const bool two_dof = d->model == CMAX_MODEL_2DOF;
     if (h->n == 0) {  // this rank holds no events of the batch
         CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
         return 0;
@@ -1159,7 +1221,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // and the per-event gather, accumulated over the reference times
     if (!two_dof) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
     const EvView ev = ev_view(h);
-    const bool fold = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
+    const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : kFoldNone);
     double k0 = 0, k1 = 0;
     if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
     for (int k = 0; k < d->n_ref; ++k) {
@@ -1181,16 +1243,20 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             gsrc = h->G;
         }
         const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t);
-        double *gpart = h->d_gpart + (int64_t)k * h->nseg * 2;
-        double *res = k == d->n_ref - 1 ? result : nullptr;  // the last K3 launch also writes the loss
+        double *gpart = h->d_gpart + (int64_t)k * h->nseg * (deferred ? 6 : 2);
+        double *res = k == d->n_ref - 1 && !deferred ? result : nullptr;  // the last K3 launch also writes the loss
+        float *zero_img = deferred && zero_next ? zero_next + k * npix : nullptr;
         switch (d->model) {
-            case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, gsrc, fold, op, k, gpart, nullptr, res, s); break;
-            case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, s); break;
-            default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, s); break;
+            case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, gsrc, fold, op, k, gpart, nullptr, res, zero_img, s); break;
+            case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, nullptr, s); break;
+            default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, nullptr, s); break;
         }
         CMAX_CHECK_LAUNCH();
     }
-    if (two_dof) {
+    if (deferred) {
+        hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_gpart, h->nseg, result, (double *)grad);
+        CMAX_CHECK_LAUNCH();
+    } else if (two_dof) {
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)grad);
         CMAX_CHECK_LAUNCH();
     }
