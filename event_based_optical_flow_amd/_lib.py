@@ -44,6 +44,31 @@ class CmaxObjective(ctypes.Structure):
     ]
 
 
+class CmaxPatchObjective(ctypes.Structure):
+    """Mirror of cmax_patch_objective_t (include/cmax_hip.h)."""
+
+    _fields_ = [
+        ("n_terms", ctypes.c_int32),
+        ("time_aware", ctypes.c_int32),
+        ("T", ctypes.c_int32),
+        ("scheme", ctypes.c_int32),
+        ("t0", ctypes.c_int32),
+        ("H", ctypes.c_int32),
+        ("W", ctypes.c_int32),
+        ("ph", ctypes.c_int32),
+        ("pw", ctypes.c_int32),
+        ("sw_h", ctypes.c_int32),
+        ("sw_w", ctypes.c_int32),
+        ("pad_h", ctypes.c_int32),
+        ("pad_w", ctypes.c_int32),
+        ("tv_omit_boundary", ctypes.c_int32),
+        ("t_scale", ctypes.c_double),
+        ("weight", ctypes.c_double * 4),
+        ("tv_weight", ctypes.c_double),
+        ("term", CmaxObjective * 4),
+    ]
+
+
 # constants (include/cmax_hip.h)
 F32, F64 = 0, 1
 MODEL_2DOF, MODEL_DENSE, MODEL_VOXEL = 0, 1, 2
@@ -86,6 +111,11 @@ SIGNATURES = {
     "cmax_read_profile": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "cmax_copy_iwe": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "cmax_handle_info": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "cmax_sizeof_patch_objective": (c_int, []),
+    "cmax_patch_plan_create": (c_int, [c_vp, ctypes.POINTER(CmaxPatchObjective), ctypes.POINTER(c_vp)]),
+    "cmax_patch_plan_destroy": (c_int, [c_vp]),
+    "cmax_patch_plan_evaluate": (c_int, [c_vp, c_vp, c_int, ctypes.POINTER(c_dbl), c_vp, c_vp]),
+    "cmax_patch_plan_hvp": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lock = threading.Lock()
@@ -124,6 +154,8 @@ def load():
             fn.argtypes = args
         if lib.cmax_sizeof_objective() != ctypes.sizeof(CmaxObjective):
             raise RuntimeError("cmax_objective_t layout mismatch between libcmax_hip.so and the ctypes binding")
+        if lib.cmax_sizeof_patch_objective() != ctypes.sizeof(CmaxPatchObjective):
+            raise RuntimeError("cmax_patch_objective_t layout mismatch between libcmax_hip.so and the ctypes binding")
         if lib.cmax_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libcmax_hip ABI {lib.cmax_abi_version()} != binding ABI {ABI_VERSION}")
         _lib = lib

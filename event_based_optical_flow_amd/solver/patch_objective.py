@@ -7,10 +7,13 @@ Equivalent of `PyramidalPatchContrastMaximization.objective_scipy`
   [+ weight * total_variation(patch motion)].
 Every stage is a HIP kernel with a hand-written adjoint; torch only chains them on the autograd tape.
 """
+import ctypes
 from typing import Dict, Optional, Tuple, Union
 
+import numpy as np
 import torch
 
+from .. import _lib
 from .. import functional as F
 from ..cmax import CMaxHandle, ContrastObjective
 
@@ -41,6 +44,83 @@ class PatchFlowObjective:
         model = "dense-flow-voxel" if self.time_aware else "dense-flow"
         self.contrast = ContrastObjective(handle, model, cost=cost, cost_with_weight=cost_with_weight, sigma=blur_sigma)
         self.device = handle.device  # read by scipy_autograd.TorchWrapper
+        self._plan = None
+        self._build_native_plan()
+
+    # -- one-call native path (cmax_patch_plan_*, csrc/cmax_solver.hip) ---------------------------------
+    def _build_native_plan(self):
+        """The same chain as `__call__` + autograd, as ONE library call per evaluation.  Available for numeric
+        hybrid weights ("inv" weights keep the autograd path)."""
+        fused = [(w, desc) for _, w, desc in self.contrast.terms if desc is not None]
+        tv = [w for name, w, desc in self.contrast.terms if desc is None]
+        if not fused or len(fused) > 4 or any(w == "inv" for w, _ in fused) or any(w == "inv" for w in tv):
+            return
+        d = _lib.CmaxPatchObjective()
+        d.n_terms = len(fused)
+        d.time_aware = int(self.time_aware)
+        d.T = self.time_bin if self.time_aware else 0
+        d.scheme = F.SCHEME_CODES.get(self.flow_interpolation, -1) if self.time_aware else 0
+        if self.time_aware and (d.scheme < 0 or self.t0_flow_location not in ("first", "middle")):
+            return
+        d.t0 = (self.time_bin // 2 if self.t0_flow_location == "middle" else 0) if self.time_aware else 0
+        d.H, d.W = self.handle.image_size
+        d.ph, d.pw = self.patch_image_size
+        d.sw_h, d.sw_w = self.sliding_window
+        d.pad_h, d.pad_w = self.pad
+        d.tv_omit_boundary = int(self.contrast.omit_boundary)
+        d.t_scale = self.t_scale
+        for i, (w, desc) in enumerate(fused):
+            d.weight[i] = float(w)
+            d.term[i] = desc
+        sign = 1.0 if self.contrast.direction == "minimize" else -1.0
+        d.tv_weight = sign * float(sum(tv)) if tv else 0.0
+        plan = ctypes.c_void_p()
+        with torch.cuda.device(self.handle.device):
+            _lib.check(_lib.load().cmax_patch_plan_create(self.handle._h, ctypes.byref(d), ctypes.byref(plan)))
+        self._plan, self._nx = plan, 2 * self.patch_image_size[0] * self.patch_image_size[1]
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan:
+            try:
+                _lib.load().cmax_patch_plan_destroy(plan)
+            except Exception:  # interpreter shutdown
+                pass
+
+    @property
+    def has_native_plan(self) -> bool:
+        """TorchWrapper calls `value_and_grad_numpy` / `hvp_numpy` when this is True."""
+        return self._plan is not None
+
+    def value_and_grad_numpy(self, x: np.ndarray, with_tv: bool = True, want_grad: bool = True):
+        """x [2*ph*pw] float64 (host) -> (loss, gradient [2*ph*pw] float64): one cmax_patch_plan_evaluate call."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        if x.size != self._nx:
+            raise ValueError(f"x has {x.size} elements, the patch grid needs {self._nx}")
+        loss = ctypes.c_double(0.0)
+        grad = np.empty(self._nx, dtype=np.float64) if want_grad else None
+        with torch.cuda.device(self.handle.device):
+            _lib.check(_lib.load().cmax_patch_plan_evaluate(self._plan, x.ctypes.data, int(with_tv), ctypes.byref(loss),
+                                                            grad.ctypes.data if want_grad else None, F._stream()))
+        return loss.value, grad
+
+    def hvp_numpy(self, x: np.ndarray, v: np.ndarray, disp_step: float = 0.05) -> np.ndarray:
+        """Hessian-vector product on host arrays: exact (cmax_patch_plan_hvp) unless time-aware, where the analytic
+        gradient of the smooth part is differenced exactly as in `hvp`."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
+        if self.time_aware:
+            vmax = float(np.abs(v).max())
+            if vmax == 0.0:
+                return np.zeros_like(v)
+            h = disp_step / (self.t_scale * vmax)
+            gp = self.value_and_grad_numpy(x + h * v, with_tv=False)[1]
+            gm = self.value_and_grad_numpy(x - h * v, with_tv=False)[1]
+            return (gp - gm) / (2.0 * h)
+        hv = np.empty(self._nx, dtype=np.float64)
+        with torch.cuda.device(self.handle.device):
+            _lib.check(_lib.load().cmax_patch_plan_hvp(self._plan, x.ctypes.data, v.ctypes.data, hv.ctypes.data, F._stream()))
+        return hv
 
     def dense_flow(self, x: torch.Tensor) -> torch.Tensor:
         """[2*ph*pw] patch motion -> [2,H,W] (or [T,2,H,W]) flow in pixel per NORMALISED time."""

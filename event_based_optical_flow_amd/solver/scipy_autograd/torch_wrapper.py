@@ -4,9 +4,11 @@ Role of the reference's `TorchWrapper` (src/solver/scipy_autograd/torch_wrapper.
 there from brunorigal/autograd-minimize): value + gradient through `torch.autograd.grad`, and a
 Hessian-vector product for Newton-CG / trust-* methods.
 
-The objective's backward pass is a hand-written HIP kernel (a torch.autograd.Function), so autograd
+An objective that advertises `has_native_plan` (PatchFlowObjective) is evaluated by ONE library call on host
+arrays (`value_and_grad_numpy`, cmax_patch_plan_evaluate) -- no torch tensors on that path.  Otherwise:
+the objective's backward pass is a hand-written HIP kernel (a torch.autograd.Function), so autograd
 cannot double-backward through it.  Hessian-vector products come from
-  * `func.hvp(x, v)` when the objective provides it: the exact product computed by
+  * `func.hvp_numpy(x, v)` / `func.hvp(x, v)` when the objective provides them: the exact product computed by
     cmax_objective_hvp (tangent image / tangent gradient kernels) -- the quantity the reference obtains
     from torch.autograd.functional.vhp; else
   * a central difference of the ANALYTIC gradient, Hv ~ [g(x + h v) - g(x - h v)] / (2h),
@@ -31,6 +33,7 @@ class TorchWrapper:
             raise ValueError
         self.hvp_type = hvp_type  # accepted for signature compatibility ("vhp" / "hvp"): both map to the difference scheme
         self.hvp_eps = hvp_eps
+        self.force_autograd = False  # True: never take the objective's one-call native path (tests compare the two)
         self.n_value_and_grad = 0
 
     # -- shape bookkeeping ---------------------------------------------------------------------
@@ -52,6 +55,10 @@ class TorchWrapper:
 
     def get_value_and_grad(self, x: np.ndarray, *args) -> Tuple[np.ndarray, np.ndarray]:
         self.n_value_and_grad += 1
+        if not args and not self.force_autograd and getattr(self.func, "has_native_plan", False):
+            # the objective runs end to end inside libcmax_hip (one call, host arrays in and out)
+            loss, grad = self.func.value_and_grad_numpy(x)
+            return np.float64(loss), grad
         xt = self._tensor(x, True)
         loss = self.func(xt, *args)
         (grad,) = torch.autograd.grad(loss, xt)
@@ -67,6 +74,9 @@ class TorchWrapper:
         vmax = np.abs(v).max()
         if vmax == 0.0:
             return np.zeros_like(v)
+        if self.hvp_type != "fd" and not self.force_autograd and getattr(self.func, "has_native_plan", False) \
+                and getattr(self.func, "has_exact_hvp", False):
+            return self.func.hvp_numpy(x, v)
         if self.hvp_type != "fd" and getattr(self.func, "has_exact_hvp", False):
             hv = self.func.hvp(self._tensor(x, False), self._tensor(v, False))
             return hv.detach().cpu().numpy().astype(np.float64).reshape(-1)

@@ -261,6 +261,47 @@ int cmax_copy_iwe(cmax_handle_t h, int k, float *iwe_out, cmax_stream_t stream);
 /* Introspection for tests / bench: number of packed events, HBM bytes held by the handle.     */
 int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_bytes);
 
+/* =============================================================================================
+ * The optimiser's objective for patch-based flow in one call: what
+ * scipy.optimize calls through TorchWrapper.get_value_and_grad / get_hvp
+ * (src/solver/scipy_autograd/torch_wrapper.py:30-73) on
+ * PyramidalPatchContrastMaximization.objective_scipy + motion_to_dense_flow
+ * (src/solver/patch_contrast_pyramid.py:430-516):
+ *   x [2,ph,pw] patch motion (host fp64, pixel per time unit)
+ *     -> dense flow (cmax_patch_to_dense) * t_scale  [-> voxel (cmax_voxel_construct)]  -> fp32
+ *     -> loss = sum_i weight_i * cmax_objective(term_i)  + tv_weight * total_variation(x)
+ *   and the gradient back through the adjoints, returned to host fp64.  One stream
+ *   synchronisation per call; intermediates live in the plan.
+ * ============================================================================================= */
+typedef struct {
+    int32_t n_terms;          /* 1..4 fused contrast terms of a hybrid cost (src/costs/hybrid.py:48-57) */
+    int32_t time_aware;       /* 0: terms use CMAX_MODEL_DENSE; 1: CMAX_MODEL_VOXEL on the propagated flow */
+    int32_t T, scheme, t0;    /* time bins, CMAX_SCHEME_*, bin that holds the patch flow (0 "first", T/2 "middle") */
+    int32_t H, W;             /* sensor size of the handle */
+    int32_t ph, pw;           /* patch grid */
+    int32_t sw_h, sw_w;       /* sliding window = up-sampling factor */
+    int32_t pad_h, pad_w;     /* replicate padding of the grid (patch_contrast_base.py:470-479) */
+    int32_t tv_omit_boundary;
+    double t_scale;           /* pixel per time unit -> pixel per normalised batch period */
+    double weight[4];
+    double tv_weight;         /* 0 = no total_variation term; sign of the cost direction included */
+    cmax_objective_t term[4];
+} cmax_patch_objective_t;
+typedef struct cmax_patch_plan_s *cmax_patch_plan_t;
+
+int cmax_sizeof_patch_objective(void);
+int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc_host, cmax_patch_plan_t *out);
+int cmax_patch_plan_destroy(cmax_patch_plan_t plan);
+/* x_host [2*ph*pw] -> *loss_host, grad_host [2*ph*pw] (NULL: value only).  with_tv = 0 leaves the
+ * total_variation term out (the smooth part, differenced for time-aware Hessian-vector products).
+ * Blocks until the result is on the host.                                                      */
+int cmax_patch_plan_evaluate(cmax_patch_plan_t plan, const double *x_host, int with_tv, double *loss_host,
+                             double *grad_host, cmax_stream_t stream);
+/* Exact Hessian-vector product w.r.t. x (t_scale^2 P^T H_flow P v, cmax_objective_hvp inside); the
+ * total_variation term has zero Hessian almost everywhere.  time_aware plans: CMAX_EINVAL.      */
+int cmax_patch_plan_hvp(cmax_patch_plan_t plan, const double *x_host, const double *v_host, double *hv_host,
+                        cmax_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,79 @@ def test_solver_objective_golden(golden, tag, scale):
     assert rel_max(grad.cpu().numpy(), g[k + "__grad"]) <= TOL
 
 
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
+@pytest.mark.parametrize("scale", [1, 3])
+def test_native_plan_matches_reference_and_autograd_path(golden, tag, scale):
+    """cmax_patch_plan_evaluate (one library call, host arrays in and out) against the reference solver's loss
+    and gradient, and against the autograd-chained path it replaces; value-only and no-TV variants."""
+    g = golden("solver_objective")
+    k = f"{tag}_s{scale}"
+    size = tuple(int(v) for v in g["image_size"])
+    ev = g["events"]
+    h = E.CMaxHandle(size).set_events(ev, time_bin=10 if tag == "burgers" else 0)
+    t_scale = ev[:, 2].max() - ev[:, 2].min()
+    obj = PatchFlowObjective(h, t_scale, g[k + "__patch_image_size"], g[k + "__patch_size"], g[k + "__sliding_window"],
+                             g[tag + "__patch_shift"], cost="hybrid", cost_with_weight=YAML_HYBRID, blur_sigma=1,
+                             time_aware=(tag == "burgers"), time_bin=10, flow_interpolation="burgers",
+                             t0_flow_location="middle")
+    assert obj.has_native_plan
+    x = np.asarray(g[k + "__x"], dtype=np.float64).reshape(-1)
+    w = TorchWrapper(obj, precision="float64", device="cuda")
+    w.get_input(g[k + "__x"])
+    loss, grad = w.get_value_and_grad(x)  # native
+    assert abs(float(loss) - g[k + "__loss"]) <= TOL * abs(g[k + "__loss"])
+    assert rel_max(grad, np.asarray(g[k + "__grad"]).reshape(-1)) <= TOL
+    w.force_autograd = True
+    loss_a, grad_a = w.get_value_and_grad(x)
+    assert abs(float(loss) - float(loss_a)) <= 1e-6 * abs(float(loss_a))
+    assert rel_max(grad, grad_a) <= 1e-5
+    # value only; repeated call (the handle's double-buffered images flip every evaluation)
+    for _ in range(3):
+        loss_v, none = obj.value_and_grad_numpy(x, want_grad=False)
+        assert none is None and abs(loss_v - float(loss)) <= 1e-9 * abs(float(loss))
+    # smooth part only == the autograd path's _smooth_grad
+    _, gs = obj.value_and_grad_numpy(x, with_tv=False)
+    gs_a = obj._smooth_grad(torch.tensor(x, dtype=torch.float64, device="cuda")).cpu().numpy().reshape(-1)
+    assert rel_max(gs, gs_a) <= 1e-5
+    with pytest.raises(ValueError):
+        obj.value_and_grad_numpy(x[:-1])
+
+
+def test_native_plan_hvp_matches_the_autograd_path(golden):
+    g = golden("solver_objective")
+    for tag in ("plain", "burgers"):
+        k = f"{tag}_s3"
+        size = tuple(int(v) for v in g["image_size"])
+        ev = g["events"]
+        h = E.CMaxHandle(size).set_events(ev, time_bin=10 if tag == "burgers" else 0)
+        obj = PatchFlowObjective(h, ev[:, 2].max() - ev[:, 2].min(), g[k + "__patch_image_size"], g[k + "__patch_size"],
+                                 g[k + "__sliding_window"], g[tag + "__patch_shift"], cost="hybrid", cost_with_weight=YAML_HYBRID,
+                                 blur_sigma=1, time_aware=(tag == "burgers"), time_bin=10)
+        x = np.asarray(g[k + "__x"], dtype=np.float64).reshape(-1)
+        v = np.random.default_rng(3).normal(size=x.shape)
+        w = TorchWrapper(obj, precision="float64", device="cuda")
+        w.get_input(x)
+        hv = w.get_hvp(x, v)  # native: exact (plain) / differenced smooth gradient (burgers)
+        w.force_autograd = True
+        hv_a = w.get_hvp(x, v)
+        assert rel_max(hv, hv_a) <= (1e-4 if tag == "plain" else 2e-3), tag
+        assert np.array_equal(w.get_hvp(x, np.zeros_like(v)), np.zeros_like(v))
+
+
+def test_native_plan_falls_back_for_inverse_weights(golden):
+    g = golden("solver_objective")
+    k = "plain_s1"
+    h = E.CMaxHandle(tuple(int(v) for v in g["image_size"])).set_events(g["events"])
+    obj = PatchFlowObjective(h, 0.05, g[k + "__patch_image_size"], g[k + "__patch_size"], g[k + "__sliding_window"],
+                             g["plain__patch_shift"], cost="hybrid",
+                             cost_with_weight={"image_variance": "inv", "total_variation": 0.01}, blur_sigma=1)
+    assert not obj.has_native_plan
+    w = TorchWrapper(obj, precision="float64", device="cuda")
+    x = w.get_input(g[k + "__x"])
+    loss, grad = w.get_value_and_grad(x)  # autograd path
+    assert np.isfinite(float(loss)) and np.isfinite(grad).all()
+
+
 def test_hvp_exact_and_difference_quotient(golden):
     """Newton-CG's hessp.  (i) Default: the exact product from cmax_objective_hvp == the reference's
     torch.autograd.functional.vhp (golden hvp.npz).  (ii) hvp_type="fd" (the fallback of time-aware

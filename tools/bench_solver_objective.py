@@ -25,14 +25,16 @@ for ta in (False, True):
     w = TorchWrapper(obj, precision="float64", device="cuda")
     x = w.get_input(np.random.default_rng(0).uniform(-100, 100, 512))
     v = np.random.default_rng(1).normal(size=512)
-    for name, fn in (("value+grad", lambda: w.get_value_and_grad(x)), ("hvp", lambda: w.get_hvp(x, v))):
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 50
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        print("%-8s %-10s %8.3f ms per call (host round trip included, %d events, 512 DoF)" % (
-            "burgers" if ta else "plain", name, (time.perf_counter() - t0) / reps * 1e3, N))
+    for path in ("native", "autograd"):  # one library call per evaluation / the autograd-chained stages
+        w.force_autograd = path == "autograd"
+        for name, fn in (("value+grad", lambda: w.get_value_and_grad(x)), ("hvp", lambda: w.get_hvp(x, v))):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 100
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            print("%-8s %-9s %-10s %8.3f ms per call (host round trip included, %d events, 512 DoF)" % (
+                "burgers" if ta else "plain", path, name, (time.perf_counter() - t0) / reps * 1e3, N))
