@@ -75,13 +75,18 @@ struct cmax_handle_s {
     uint2 *evp = nullptr;  // packed events, 8 B each, 16-byte aligned base (+2 elements of padding)
     float *rx = nullptr, *ry = nullptr;
     double *tau64 = nullptr;
+    // second set for re-ordering by (tile, time bin) (binned handles only; swapped with the first after a re-sort)
+    uint2 *evp_alt = nullptr;
+    float *rx_alt = nullptr, *ry_alt = nullptr;
+    double *tau64_alt = nullptr;
+    int64_t cap_alt = 0;
     // sort scratch
     uint32_t *key_tmp = nullptr;
     int *counts = nullptr;  // [nkeys + 1] -> offsets after the scan
     int *cursor = nullptr;  // [nkeys]
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events
-    int *d_tile_start = nullptr;  // [ntiles + 1] first sorted event of every source tile
+    int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int nseg = 0, seg_cap = 0;
     // images
@@ -246,16 +251,50 @@ k_scatter(const T *__restrict__ ev, int64_t n, const uint32_t *__restrict__ key,
     }
 }
 
-// first sorted event of every source tile (offsets[] holds one entry per source PIXEL key)
-__global__ void __launch_bounds__(256) k_tile_starts(const int *__restrict__ offsets, int ntiles, int *__restrict__ tile_start) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t <= ntiles) tile_start[t] = offsets[t * (kTile * kTile)];
+// first sorted event of every group: offsets[] holds one entry per sort key, a group = `stride` consecutive keys
+// (256 pixel keys of a source tile, or one (tile, time bin) key)
+__global__ void __launch_bounds__(256) k_group_starts(const int *__restrict__ offsets, int ngroups, int stride, int *__restrict__ group_start) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g <= ngroups) group_start[g] = offsets[(int64_t)g * stride];
 }
 
-__global__ void __launch_bounds__(256) k_rebin(int64_t n, const double *__restrict__ tau64, int n_time_bin, uint2 *__restrict__ evp) {
+// Re-order the packed events for a (new) number of time bins.
+//   T > 0 : key = tile * T + bin.  The voxel model accumulates flow gradients per (pixel, bin) cell in LDS; with
+//           the events of a tile grouped by bin a workgroup touches 1-4 bins instead of all T, so its accumulator
+//           flush is T/3 times denser (cfg4 K3 26 -> see profiles), and neighbouring lanes hit different pixels
+//           (no same-address LDS atomics).  Pixel order inside a group is not needed by that path.
+//   T == 0: tile-major pixel key (the dense model's segmented scan wants equal pixels adjacent).
+__device__ __forceinline__ uint32_t resort_key(uint32_t pk, int T, int ntc) {
+    const int ix = (int)(pk & 0xFFFu), iy = (int)((pk >> 12) & 0xFFFu);
+    const int tile = (ix / kTile) * ntc + (iy / kTile);
+    if (T > 0) return (uint32_t)(tile * T) + (pk >> 24);
+    return (uint32_t)(tile * (kTile * kTile) + (ix % kTile) * kTile + (iy % kTile));
+}
+
+__global__ void __launch_bounds__(256)
+k_rekey_hist(int64_t n, const double *__restrict__ tau64, int T, int ntc, uint2 *__restrict__ evp, uint32_t *__restrict__ key,
+             int *__restrict__ counts) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t bin = n_time_bin > 0 ? (uint32_t)voxel_bin(tau64[i], n_time_bin) : 0u;
-        evp[i].x = (evp[i].x & 0x00FFFFFFu) | (bin << 24);
+        const uint32_t bin = T > 0 ? (uint32_t)voxel_bin(tau64[i], T) : 0u;
+        const uint32_t pk = (evp[i].x & 0x00FFFFFFu) | (bin << 24);
+        evp[i].x = pk;
+        const uint32_t k = resort_key(pk, T, ntc);
+        key[i] = k;
+        atomicAdd(&counts[k], 1);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_rescatter(int64_t n, const uint32_t *__restrict__ key, const int *__restrict__ offsets, int *__restrict__ cursor,
+            const uint2 *__restrict__ evp, const float *__restrict__ rx, const float *__restrict__ ry, const double *__restrict__ tau64,
+            uint2 *__restrict__ evp2, float *__restrict__ rx2, float *__restrict__ ry2, double *__restrict__ tau2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = key[i];
+        const int pos = offsets[k] + atomicAdd(&cursor[k], 1);
+        evp2[pos] = evp[i];
+        rx2[pos] = rx[i];
+        ry2[pos] = ry[i];
+        tau2[pos] = tau64[i];
     }
 }
 
@@ -887,6 +926,106 @@ static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, 
     return 0;
 }
 
+// Work list of the event kernels from the sorted events.  counts[] = exclusive scan of the sort-key histogram;
+// a GROUP = `stride` consecutive keys = one source tile (pixel keys) or one (tile, time bin).
+// Segments: <= kSegMax consecutive sorted events (fixed-point range) inside one tile row, spanning <= 12 groups
+// (the flow-gradient accumulator of the voxel K3 holds kAccCells = 12 * 256 cells).  Two regimes, measured on MI355X:
+//   * batches that fill the chip several times over (> 1024 full segments): cut every kSegMax events, group
+//     boundaries ignored -- every workgroup full (dense K3 of cfg3 30 -> 25 us);
+//   * smaller batches are latency-bound: small groups are merged while they fit, a group with more than
+//     kSegMax events is split into EQUAL parts -- group-aligned windows are tighter and no workgroup is left
+//     with a small remainder (cfg2: 2040 + 806 per tile -> 2 x 1423).
+static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
+    const int T = stride == 1 ? h->n_time_bin : 1;  // groups per tile
+    const int ngroups = h->ntr * h->ntc * T;
+    hipLaunchKernelGGL(k_group_starts, dim3(div_up(ngroups + 1, 256)), dim3(256), 0, s, h->counts, ngroups, stride, h->d_tile_start);
+    CMAX_CHECK_LAUNCH();
+    std::vector<int> group_start((size_t)ngroups + 1);
+    CMAX_CHECK_HIP(hipMemcpyAsync(group_start.data(), h->d_tile_start, group_start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    CMAX_CHECK_HIP(hipStreamSynchronize(s));
+    const int max_groups = kAccCells / 256;
+    const bool free_cut = h->n > (int64_t)1024 * kSegMax;
+    std::vector<int4> segs;
+    int begin = 0, count = 0, row_of_begin = -1, g0 = 0, g_last = 0;
+    auto close = [&]() {
+        if (count > 0) segs.push_back(make_int4(begin, count, g0, g_last - g0 + 1));
+        count = 0;
+    };
+    for (int g = 0; g < ngroups; ++g) {
+        int b = group_start[g], c = group_start[g + 1] - group_start[g];
+        const int trow = (g / T) / h->ntc;
+        if (c == 0) continue;
+        if (count > 0 && (trow != row_of_begin || g - g0 + 1 > max_groups || (!free_cut && count + c > kSegMax))) close();
+        int limit = kSegMax;
+        if (!free_cut && c > kSegMax) {
+            const int parts = (c + kSegMax - 1) / kSegMax;
+            limit = (c + parts - 1) / parts;
+        }
+        while (c > 0) {
+            if (count == 0) {
+                begin = b;
+                row_of_begin = trow;
+                g0 = g;
+            }
+            g_last = g;
+            const int take = c < limit - count ? c : limit - count;
+            count += take;
+            b += take;
+            c -= take;
+            if (count >= limit) close();
+        }
+    }
+    close();
+    h->nseg = (int)segs.size();
+    if (h->nseg > h->seg_cap) {
+        dev_free(&h->d_segs);
+        dev_free(&h->d_gpart);
+        int rc = dev_alloc(h, &h->d_segs, h->nseg);
+        if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 6);
+        if (rc) return rc;
+        h->seg_cap = h->nseg;
+    }
+    if (h->nseg > 0) {
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        CMAX_CHECK_HIP(hipStreamSynchronize(s));  // `segs` is a host temporary
+    }
+    return 0;
+}
+
+// Re-bin the packed events for h->n_time_bin and re-order them: by (tile, bin) when binned, by tile-major pixel
+// otherwise (see resort_key).  Followed by the work list.
+static int resort_events(cmax_handle_s *h, hipStream_t s) {
+    const int64_t n = h->n;
+    const int T = h->n_time_bin;
+    if (h->cap_alt < h->cap) {
+        CMAX_CHECK_HIP(hipStreamSynchronize(s));
+        dev_free(&h->evp_alt);
+        dev_free(&h->rx_alt);
+        dev_free(&h->ry_alt);
+        dev_free(&h->tau64_alt);
+        int rc = dev_alloc(h, &h->evp_alt, h->cap + 2);
+        if (!rc) rc = dev_alloc(h, &h->rx_alt, h->cap);
+        if (!rc) rc = dev_alloc(h, &h->ry_alt, h->cap);
+        if (!rc) rc = dev_alloc(h, &h->tau64_alt, h->cap);
+        if (rc) return rc;
+        h->cap_alt = h->cap;
+    }
+    const int nkeys = T > 0 ? h->ntr * h->ntc * T : h->nkeys;  // <= h->nkeys: T <= 255 < 256 pixels per tile
+    CMAX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)(nkeys + 1) * sizeof(int), s));
+    CMAX_CHECK_HIP(hipMemsetAsync(h->cursor, 0, (size_t)nkeys * sizeof(int), s));
+    const int grid = stream_grid(n, 256);
+    hipLaunchKernelGGL(k_rekey_hist, dim3(grid), dim3(256), 0, s, n, h->tau64, T, h->ntc, h->evp, h->key_tmp, h->counts);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, h->counts, nkeys);
+    hipLaunchKernelGGL(k_rescatter, dim3(grid), dim3(256), 0, s, n, h->key_tmp, h->counts, h->cursor, h->evp, h->rx, h->ry, h->tau64,
+                       h->evp_alt, h->rx_alt, h->ry_alt, h->tau64_alt);
+    CMAX_CHECK_LAUNCH();
+    std::swap(h->evp, h->evp_alt);
+    std::swap(h->rx, h->rx_alt);
+    std::swap(h->ry, h->ry_alt);
+    std::swap(h->tau64, h->tau64_alt);
+    return build_segments(h, T > 0 ? 1 : 256, s);
+}
+
 }  // namespace cmax
 
 using namespace cmax;
@@ -922,7 +1061,7 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     if (!rc) rc = dev_alloc(h, &h->counts, h->nkeys + 1);
     if (!rc) rc = dev_alloc(h, &h->cursor, h->nkeys);
     if (!rc) rc = dev_alloc(h, &h->d_flags, 2);
-    if (!rc) rc = dev_alloc(h, &h->d_tile_start, h->ntr * h->ntc + 1);
+    if (!rc) rc = dev_alloc(h, &h->d_tile_start, h->ntr * h->ntc * 256 + 1);  // up to 255 time bins per tile
     if (rc) {
         cmax_destroy(h);
         return rc;
@@ -952,6 +1091,10 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->ry);
     dev_free(&h->tau64);
     dev_free(&h->key_tmp);
+    dev_free(&h->evp_alt);
+    dev_free(&h->rx_alt);
+    dev_free(&h->ry_alt);
+    dev_free(&h->tau64_alt);
     for (int c = 0; c < 4; ++c)
         for (hipEvent_t e : h->prof_ev[c]) (void)hipEventDestroy(e);
     delete h;
@@ -982,6 +1125,11 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         if (!rc) rc = dev_alloc(h, &h->key_tmp, n);
         if (rc) return rc;
         h->cap = n;
+        dev_free(&h->evp_alt);  // re-allocated by the next re-sort
+        dev_free(&h->rx_alt);
+        dev_free(&h->ry_alt);
+        dev_free(&h->tau64_alt);
+        h->cap_alt = 0;
     }
     // global time extremes
     if (have_tminmax) {
@@ -1008,79 +1156,18 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     if (dtype == CMAX_F32) hipLaunchKernelGGL(k_scatter<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
     else hipLaunchKernelGGL(k_scatter<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
     CMAX_CHECK_LAUNCH();
-    // once per batch: how many events survived, whether any source coordinate is fractional, and the
-    // per-tile event ranges from which the segment work list is cut
-    const int ntiles = h->ntr * h->ntc;
-    hipLaunchKernelGGL(k_tile_starts, dim3(div_up(ntiles + 1, 256)), dim3(256), 0, s, h->counts, ntiles, h->d_tile_start);
-    CMAX_CHECK_LAUNCH();
+    // once per batch: how many events survived and whether any source coordinate is fractional
     int flags[2] = {0, 0};
-    std::vector<int> tile_start((size_t)ntiles + 1);
     double tmm_host[2] = {0.0, 0.0};
     CMAX_CHECK_HIP(hipMemcpyAsync(tmm_host, h->d_tmm, sizeof(tmm_host), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipMemcpyAsync(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
-    CMAX_CHECK_HIP(hipMemcpyAsync(tile_start.data(), h->d_tile_start, tile_start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
     h->has_frac = flags[0] != 0;
     h->n = n - flags[1];
     h->tmin_host = tmm_host[0];
     h->tmax_host = tmm_host[1];
-    // Segments = the work items of the event kernels: <= kSegMax consecutive sorted events (fixed-point range)
-    // inside one tile row, spanning <= max_tiles source tiles (the flow-gradient accumulator of the voxel K3
-    // holds kAccCells cells = tiles * 256 pixels * time bins).  Two regimes, measured on MI355X:
-    //   * batches that fill the chip several times over (> 1024 full segments): cut every kSegMax events, tile
-    //     boundaries ignored -- every workgroup full (dense K3 of cfg3 30 -> 25 us);
-    //   * smaller batches are latency-bound: small tiles are merged while they fit, a tile with more than
-    //     kSegMax events is split into EQUAL parts -- tile-aligned windows are tighter and no workgroup is left
-    //     with a small remainder (cfg2: 2040 + 806 per tile -> 2 x 1423).
-    const int bins = n_time_bin > 0 ? n_time_bin : 1;
-    int max_tiles = kAccCells / (256 * bins);
-    if (max_tiles < 1) max_tiles = 1;
-    const bool free_cut = h->n > (int64_t)1024 * kSegMax;
-    std::vector<int4> segs;
-    int begin = 0, count = 0, row_of_begin = -1, tile0 = 0, tile_last = 0;
-    auto close = [&]() {
-        if (count > 0) segs.push_back(make_int4(begin, count, tile0, tile_last - tile0 + 1));
-        count = 0;
-    };
-    for (int t = 0; t < ntiles; ++t) {
-        int b = tile_start[t], c = tile_start[t + 1] - tile_start[t];
-        const int trow = t / h->ntc;
-        if (c == 0) continue;
-        if (count > 0 && (trow != row_of_begin || t - tile0 + 1 > max_tiles || (!free_cut && count + c > kSegMax))) close();
-        int limit = kSegMax;
-        if (!free_cut && c > kSegMax) {
-            const int parts = (c + kSegMax - 1) / kSegMax;
-            limit = (c + parts - 1) / parts;
-        }
-        while (c > 0) {
-            if (count == 0) {
-                begin = b;
-                row_of_begin = trow;
-                tile0 = t;
-            }
-            tile_last = t;
-            const int take = c < limit - count ? c : limit - count;
-            count += take;
-            b += take;
-            c -= take;
-            if (count >= limit) close();
-        }
-    }
-    close();
-    h->nseg = (int)segs.size();
-    if (h->nseg > h->seg_cap) {
-        dev_free(&h->d_segs);
-        dev_free(&h->d_gpart);
-        int rc = dev_alloc(h, &h->d_segs, h->nseg);
-        if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 6);
-        if (rc) return rc;
-        h->seg_cap = h->nseg;
-    }
-    if (h->nseg > 0) {
-        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        CMAX_CHECK_HIP(hipStreamSynchronize(s));  // `segs` is a host temporary
-    }
-    return 0;
+    if (n_time_bin > 0) return resort_events(h, s);  // (tile, bin) order + work list
+    return build_segments(h, 256, s);
 }
 
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
@@ -1089,9 +1176,7 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     if (n_time_bin == h->n_time_bin) return 0;
     h->n_time_bin = n_time_bin;
     if (h->n == 0) return 0;
-    hipLaunchKernelGGL(k_rebin, dim3(stream_grid(h->n, 256)), dim3(256), 0, (hipStream_t)stream, h->n, h->tau64, n_time_bin, h->evp);
-    CMAX_CHECK_LAUNCH();
-    return 0;
+    return resort_events(h, (hipStream_t)stream);
 }
 
 int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac, int normalize_t,

@@ -23,7 +23,7 @@ with open(out + "/kernel_stats.txt", "w") as f:
         f.write("%-96s %6d %9.2f %9.2f %9.2f %11.1f\n" % (k[:96], len(v), sum(v) / len(v), min(v), max(v), sum(v)))
 hot = [(k, v) for k, v in rows if "cmax::k_" in k and len(v) >= 20 or "fillBuffer" in k]
 import re
-print("[%s] " % tag + "  ".join("%s %.2f" % (re.search(r"cmax::(k_\w+)", k).group(1) if "cmax" in k else "memset", sum(v) / len(v)) for k, v in hot))
+print("[%s] " % tag + "  ".join("%s %.2f" % (re.search(r"cmax::(?:t\d+::)?(k_\w+)", k).group(1) if "cmax" in k else "memset", sum(v) / len(v)) for k, v in hot))
 import json
 for line in open(out + "/bench.log"):
     if line.startswith("{"):

@@ -24,7 +24,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in d.items():
         if "cmax::k_" in k and len(v) >= 10:
             import re
-            name = re.search(r"cmax::(k_\w+)", k).group(1)
+            name = re.search(r"cmax::(?:t\d+::)?(k_\w+)", k).group(1)
             res.setdefault(name, {})[ctr] = sum(v) / len(v)
 print(json.dumps(res, indent=1))
 json.dump(res, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1)
