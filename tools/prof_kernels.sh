@@ -21,7 +21,8 @@ with open(out + "/kernel_stats.txt", "w") as f:
     f.write("%-96s %6s %9s %9s %9s %11s\n" % ("kernel", "calls", "avg_us", "min_us", "max_us", "total_us"))
     for k, v in rows:
         f.write("%-96s %6d %9.2f %9.2f %9.2f %11.1f\n" % (k[:96], len(v), sum(v) / len(v), min(v), max(v), sum(v)))
-hot = [(k, v) for k, v in rows if "cmax::k_" in k and len(v) >= 20 or "fillBuffer" in k]
+import re
+hot = [(k, v) for k, v in rows if re.search(r"cmax::(?:t\d+::)?k_", k) and len(v) >= 20 or "fillBuffer" in k]
 import re
 print("[%s] " % tag + "  ".join("%s %.2f" % (re.search(r"cmax::(?:t\d+::)?(k_\w+)", k).group(1) if "cmax" in k else "memset", sum(v) / len(v)) for k, v in hot))
 import json

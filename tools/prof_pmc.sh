@@ -22,8 +22,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if row["Counter_Name"] == ctr:
             d[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     for k, v in d.items():
-        if "cmax::k_" in k and len(v) >= 10:
-            import re
+        import re
+        if re.search(r"cmax::(?:t\d+::)?k_", k) and len(v) >= 10:
             name = re.search(r"cmax::(?:t\d+::)?(k_\w+)", k).group(1)
             res.setdefault(name, {})[ctr] = sum(v) / len(v)
 print(json.dumps(res, indent=1))
