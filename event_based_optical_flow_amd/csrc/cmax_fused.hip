@@ -85,7 +85,8 @@ struct cmax_handle_s {
     int *counts = nullptr;  // [nkeys + 1] -> offsets after the scan
     int *cursor = nullptr;  // [nkeys]
     int nkeys = 0, ntr = 0, ntc = 0;
-    int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events
+    int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] source pixels with >= 1 event
+    bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
     int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int nseg = 0, seg_cap = 0;
@@ -195,7 +196,7 @@ k_pack_hist(const T *__restrict__ ev, int64_t n, int H, int W, int ntc, uint32_t
         if (fx >= (T)0 && fx < (T)H && fy >= (T)0 && fy < (T)W) {  // NaN fails every comparison -> dropped
             int ix = (int)fx, iy = (int)fy;
             k = (uint32_t)(((ix / kTile) * ntc + (iy / kTile)) * (kTile * kTile) + (ix % kTile) * kTile + (iy % kTile));
-            atomicAdd(&counts[k], 1);
+            if (atomicAdd(&counts[k], 1) == 0) atomicAdd(&flags[2], 1);
             if (x != fx || y != fy) flags[0] = 1;
         } else {
             atomicAdd(&flags[1], 1);
@@ -810,8 +811,16 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
                         const ObjParams &op, int k, double *gpart, float *gflow, double *result, float *zero_img, hipStream_t s) {
     const int grid = 8 * ((h->nseg + 7) / 8);
     ProfScope prof(h, kProfGrad, s);
-#define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result, zero_img)
+    // dense model: runs of equal source pixel are reduced serially per thread when they are long (pixel-sorted
+    // handle, >= 8 events per active pixel), else with a segmented scan per slot over lanes holding consecutive events
+    const bool strided = MODEL == CMAX_MODEL_DENSE && !(h->long_runs && h->n_time_bin == 0);
+#define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, STRIDED) \
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, STRIDED>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result, zero_img)
+#define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
+    if constexpr (MODEL == CMAX_MODEL_DENSE) {                                \
+        if (strided) CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, true);                \
+        else CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false);                       \
+    } else CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false)
 #define CMAX_LAUNCH_GRAD_FR(NS, FRAC)                                                  \
     if (fold == kFoldDeferred) {                                                       \
         if constexpr (MODEL == CMAX_MODEL_2DOF) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); \
@@ -833,6 +842,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 #undef CMAX_LAUNCH_GRAD_NS
 #undef CMAX_LAUNCH_GRAD_FR
 #undef CMAX_LAUNCH_GRAD
+#undef CMAX_LAUNCH_GRAD_L
 }
 
 static EvView ev_view(const cmax_handle_s *h) {
@@ -1060,7 +1070,7 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     if (!rc) rc = dev_alloc(h, &h->d_stat, kStatSlots * kStatStride);
     if (!rc) rc = dev_alloc(h, &h->counts, h->nkeys + 1);
     if (!rc) rc = dev_alloc(h, &h->cursor, h->nkeys);
-    if (!rc) rc = dev_alloc(h, &h->d_flags, 2);
+    if (!rc) rc = dev_alloc(h, &h->d_flags, 4);
     if (!rc) rc = dev_alloc(h, &h->d_tile_start, h->ntr * h->ntc * 256 + 1);  // up to 255 time bins per tile
     if (rc) {
         cmax_destroy(h);
@@ -1142,7 +1152,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     CMAX_CHECK_LAUNCH();
     CMAX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)(h->nkeys + 1) * sizeof(int), s));
     CMAX_CHECK_HIP(hipMemsetAsync(h->cursor, 0, (size_t)h->nkeys * sizeof(int), s));
-    CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags, 0, 2 * sizeof(int), s));
+    CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
     h->n_time_bin = n_time_bin;
     if (n == 0) {
         h->has_frac = false;
@@ -1157,13 +1167,14 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     else hipLaunchKernelGGL(k_scatter<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
     CMAX_CHECK_LAUNCH();
     // once per batch: how many events survived and whether any source coordinate is fractional
-    int flags[2] = {0, 0};
+    int flags[4] = {0, 0, 0, 0};
     double tmm_host[2] = {0.0, 0.0};
     CMAX_CHECK_HIP(hipMemcpyAsync(tmm_host, h->d_tmm, sizeof(tmm_host), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipMemcpyAsync(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
     h->has_frac = flags[0] != 0;
     h->n = n - flags[1];
+    h->long_runs = flags[2] > 0 && h->n >= (int64_t)8 * flags[2];
     h->tmin_host = tmm_host[0];
     h->tmax_host = tmm_host[1];
     if (n_time_bin > 0) return resort_events(h, s);  // (tile, bin) order + work list

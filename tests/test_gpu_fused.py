@@ -137,6 +137,23 @@ def test_cfg3_dense_gradmag():
     assert rel_max(grads[0], ref["grad"]) <= TOL
 
 
+@pytest.mark.parametrize("n,cost,sigma", [(150_000, "image_variance", 0), (150_000, "image_variance", 1), (9_000, "gradient_magnitude", 0)])
+def test_dense_gradient_run_reduction_regimes(n, cost, sigma):
+    """The dense flow gradient sums runs of equal source pixel: serially per thread when a pixel holds >= 8
+    events on average (150k events on 60x80 = 31 per pixel), with a per-slot segmented scan otherwise (9k = 1.9
+    per pixel).  Hot pixels (every 7th event lands on one of 5 pixels) give runs that span many threads and waves."""
+    size = (60, 80)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=61)
+    hot = np.arange(0, n, 7)
+    ev[hot, 0] = 10 + (hot % 5)
+    ev[hot, 1] = 20
+    flow = E.utils.generate_smooth_flow(size, 12, seed=62)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost=cost, sigma=sigma)
+    loss, grads, h = fused_eval(size, ev, flow, "dense-flow", cost, sigma)
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
 def test_cfg4_burgers_voxel_variance():
     size, n, Tn = (130, 173), 300_000, 10
     ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=49)
