@@ -362,7 +362,7 @@ struct Window {
 // how K3 obtains dL/dIWE: from a materialised G image; folded G = c2 (IWE - mu) with the statistics K2 left in
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
-constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2;
+constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3;  // kFoldScale: G image stored without its chain factor
 constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
@@ -463,8 +463,24 @@ __device__ __forceinline__ double region_pixels(int H, int W, int omit) {
     return (double)(H - 2 * i0) * (double)(W - 2 * i0);
 }
 
-// sum of the sub-accumulators of one slot
+// sum of the sub-accumulators of one slot.  WAVE: called by a whole converged wave -- lane u loads accumulator u,
+// DPP reduction, broadcast from lane 63 (a serial walk over up to 32 addresses costs the event kernels 2-4 us of
+// dependent scalar-load latency at the head of every workgroup).
+template <bool WAVE = false>
 __device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int slot, int nsub, double (&acc)[2]) {
+    if (WAVE) {
+        const int lane = threadIdx.x & (kWave - 1);
+        double a0 = 0.0, a1 = 0.0;
+        if (lane < nsub) {
+            a0 = stat[slot * kStatStride + 2 * lane];
+            a1 = stat[slot * kStatStride + 2 * lane + 1];
+        }
+        a0 = wave_sum_lane63(a0);
+        a1 = wave_sum_lane63(a1);
+        acc[0] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a0), kWave - 1), __builtin_amdgcn_readlane(__double2loint(a0), kWave - 1));
+        acc[1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a1), kWave - 1), __builtin_amdgcn_readlane(__double2loint(a1), kWave - 1));
+        return;
+    }
     acc[0] = 0.0;
     acc[1] = 0.0;
     for (int u = 0; u < nsub; ++u) {
@@ -473,24 +489,26 @@ __device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int sl
     }
 }
 
+template <bool WAVE = false>
 __device__ __forceinline__ double orig_value(const ObjParams &op, const double *stat) {
     // orig_iwe is NOT boundary-cropped for the variance (normalized_image_variance.py:40-41)
     const int omit_o = op.cost == CMAX_COST_VARIANCE ? 0 : op.omit;
     double acc[2];
-    stat_sum(stat, 4, op.nsub, acc);
+    stat_sum<WAVE>(stat, 4, op.nsub, acc);
     return contrast_value(op.cost, acc, region_pixels(op.H, op.W, omit_o), nullptr);
 }
 
 // dL/dv_k: chain factor of reference time k, and the mean of its image (variance)
+template <bool WAVE = false>
 __device__ __forceinline__ double chain_coef(const ObjParams &op, const double *stat, int k, double *mu_out) {
     const double npix = region_pixels(op.H, op.W, op.omit);
     double acc[2];
-    stat_sum(stat, k, op.nsub, acc);
+    stat_sum<WAVE>(stat, k, op.nsub, acc);
     const double v = contrast_value(op.cost, acc, npix, mu_out);
     double coef;
     if (!op.normalized) coef = op.mult[k] * (op.minimize ? -1.0 : 1.0);
     else {
-        const double v_orig = orig_value(op, stat);
+        const double v_orig = orig_value<WAVE>(op, stat);
         coef = op.mult[k] * (op.minimize ? -v_orig / (v * v) : 1.0 / v_orig);
     }
     return op.negate ? -coef : coef;
@@ -515,8 +533,11 @@ __device__ void write_result(const ObjParams &op, const double *stat, double *__
 
 template <int COST>
 __global__ void __launch_bounds__(256)
-k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot, float *__restrict__ zero_img) {
+k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot, float *__restrict__ zero_img,
+        float4 *__restrict__ zero_extra, int64_t n_extra4) {
     __shared__ double smem[2 * 4];
+    // the flow-gradient buffer K3 accumulates into is cleared here (a hipMemsetAsync node costs 4-5 us)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     const unsigned stride = gridDim.x * 256u;
@@ -558,6 +579,29 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
     }
 }
 
+// K2 + K2b in one pass for the gradient-magnitude cost: statistics as k_stats<GRADMAG>, and the UNSCALED
+// G' = (2 / n) / 8 * Sobel^T (gx, gy) 1_Omega  -- the chain factor of the objective (which needs the statistics of
+// every image) is applied by K3 when it loads its window (kFoldScale), and commutes with the blur transpose.
+__global__ void __launch_bounds__(256)
+k_stats_gimage_gm(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot,
+                  float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4, float *__restrict__ G) {
+    __shared__ double smem[2 * 4];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned npix = (unsigned)H * (unsigned)W;
+    const int i0 = omit ? 1 : 0;
+    const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0);
+    double v[2] = {0.0, 0.0};
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+        const int r = (int)(p / (unsigned)W), c = (int)(p - (unsigned)r * (unsigned)W);
+        float gx, gy;
+        G[p] = gscale * sobel8_adj_f32(img, H, W, i0, r, c, &gx, &gy);
+        if (r >= i0 && r < H - i0 && c >= i0 && c < W - i0) v[0] += (double)(gx * gx + gy * gy);
+        if (zero_img) zero_img[p] = 0.f;
+    }
+    block_sum<2>(v, smem);
+    if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
+}
+
 __global__ void k_finalize(ObjParams op, const double *__restrict__ stat, double *__restrict__ result) {
     if (threadIdx.x == 0 && blockIdx.x == 0) write_result(op, stat, result);
 }
@@ -571,7 +615,7 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
     const int i0 = op.omit ? 1 : 0;
     const double npix = region_pixels(H, W, op.omit);
     double mu = 0.0;
-    const double coef = chain_coef(op, stat, k, &mu);
+    const double coef = chain_coef<true>(op, stat, k, &mu);  // every wave is converged here
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)H * W) return;
     const int i = (int)(p / W), j = (int)(p % W);
@@ -825,6 +869,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     if (fold == kFoldDeferred) {                                                       \
         if constexpr (MODEL == CMAX_MODEL_2DOF) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); \
     } else if (fold == kFoldStats) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);             \
+    else if (fold == kFoldScale) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldScale);               \
     else CMAX_LAUNCH_GRAD(NS, FRAC, kFoldNone);
 #define CMAX_LAUNCH_GRAD_NS(NS)          \
     if (h->has_frac) {                   \
@@ -921,16 +966,18 @@ static int stat_subs(const cmax_handle_s *h) {
     return n < 4 ? 4 : (n > kStatSub ? kStatSub : n);
 }
 
-static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, int slot, float *zero_img, hipStream_t s) {
+// zero_extra: optional buffer of n_extra floats (16-byte aligned, n_extra % 4 == 0) cleared by the same launch
+static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, int slot, float *zero_img, hipStream_t s,
+                        float *zero_extra = nullptr, int64_t n_extra = 0) {
     const int grid = stat_blocks(h);
     const int nsub = stat_subs(h);
     double *stat_slot = h->d_stat + slot * kStatStride;
     ProfScope prof(h, kProfStats, s);
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
         if (cost == CMAX_COST_VARIANCE)
-            hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img);
+            hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img, (float4 *)zero_extra, n_extra / 4);
         else
-            hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img);
+            hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img, (float4 *)zero_extra, n_extra / 4);
     }
     CMAX_CHECK_LAUNCH();
     return 0;
@@ -1293,14 +1340,20 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     const bool two_dof = d->model == CMAX_MODEL_2DOF;
     const bool fold_var = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
     const bool deferred = grad && two_dof && fold_var && h->n > 0 && npix <= (int64_t)h->nseg * 8192;
+    // gradient magnitude with a gradient: K2 and K2b are one kernel (statistics + G image without its chain factor)
+    const bool fused_gm = grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
+    const bool grad_cleared_by_stats = grad && !two_dof && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
     // contrast statistics per reference time
     for (int k = 0; k < d->n_ref; ++k) {
         const float *img = nullptr;
         rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
         if (rc) return rc;
         h->last_iwe[k] = img;
-        if (deferred) continue;
-        rc = launch_stats(h, d->cost, img, d->omit_boundary, k, zero_next ? zero_next + k * npix : nullptr, s);
+        if (deferred || fused_gm) continue;  // statistics come from K3 / from k_stats_gimage_gm in the backward loop
+        // the first statistics launch also clears the flow-gradient buffer when its size and alignment allow
+        const bool clear_grad = k == 0 && grad_cleared_by_stats;
+        rc = launch_stats(h, d->cost, img, d->omit_boundary, k, zero_next ? zero_next + k * npix : nullptr, s,
+                          clear_grad ? (float *)grad : nullptr, clear_grad ? gcount : 0);
         if (rc) return rc;
     }
     if (!grad || h->n == 0) {  // value only (or a rank without events): the loss needs its own tiny launch
@@ -1315,16 +1368,23 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
     // backward: dL/dIWE (folded into K3 for the plain variance; otherwise G image + blur transpose)
     // and the per-event gather, accumulated over the reference times
-    if (!two_dof) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+    if (!two_dof && !grad_cleared_by_stats) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
     const EvView ev = ev_view(h);
-    const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : kFoldNone);
+    const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : (fused_gm ? kFoldScale : kFoldNone));
     double k0 = 0, k1 = 0;
     if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
     for (int k = 0; k < d->n_ref; ++k) {
         const float *gsrc = h->last_iwe[k];
-        if (!fold) {
+        if (fold == kFoldNone || fold == kFoldScale) {
             float *Gk = d->sigma > 0 ? h->Gt : h->G;
-            {
+            if (fused_gm) {
+                const bool clear_grad = k == 0 && grad_cleared_by_stats;
+                ProfScope prof(h, kProfStats, s);
+                for (int rep = 0; rep < h->prof_repeat; ++rep)
+                    hipLaunchKernelGGL(k_stats_gimage_gm, dim3(stat_blocks(h)), dim3(256), 0, s, h->last_iwe[k], Hp, Wp, d->omit_boundary, op.nsub,
+                                       h->d_stat + k * kStatStride, zero_next ? zero_next + k * npix : nullptr,
+                                       clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0, Gk);
+            } else {
                 ProfScope prof(h, kProfGimage, s);
                 for (int rep = 0; rep < h->prof_repeat; ++rep) {
                     if (d->cost == CMAX_COST_VARIANCE)

@@ -101,7 +101,9 @@ __device__ __forceinline__ void sobel8_f32(const float *__restrict__ img, int H,
 
 // sum_{q in Omega reading p} gx(q) SX + gy(q) SY from one 5x5 neighbourhood held in registers
 // (25 loads per pixel instead of 9 x 8); gx, gy include the /8.
-__device__ __forceinline__ float sobel8_adj_f32(const float *__restrict__ img, int H, int W, int i0, int i, int j) {
+// gx0, gy0 (optional): the Sobel/8 response AT (i, j) from the same registers
+__device__ __forceinline__ float sobel8_adj_f32(const float *__restrict__ img, int H, int W, int i0, int i, int j,
+                                                float *gx0 = nullptr, float *gy0 = nullptr) {
     float v[5][5];
 #pragma unroll
     for (int a = 0; a < 5; ++a)
@@ -110,6 +112,10 @@ __device__ __forceinline__ float sobel8_adj_f32(const float *__restrict__ img, i
             const int r = i + a - 2, c = j + b - 2;
             v[a][b] = (r < 0 || r >= H || c < 0 || c >= W) ? 0.f : img[(int64_t)r * W + c];
         }
+    if (gx0) {
+        *gx0 = ((v[3][1] + 2.f * v[3][2] + v[3][3]) - (v[1][1] + 2.f * v[1][2] + v[1][3])) * 0.125f;
+        *gy0 = ((v[1][3] + 2.f * v[2][3] + v[3][3]) - (v[1][1] + 2.f * v[2][1] + v[3][1])) * 0.125f;
+    }
     float s = 0.f;
 #pragma unroll
     for (int a = -1; a <= 1; ++a)
