@@ -28,6 +28,7 @@
 //
 // fp32 per event with the integer source pixel split from the fp32 displacement (keeps the
 // bilinear fractions accurate to ulp(displacement) instead of ulp(coordinate)); fp64 reductions.
+#include <algorithm>
 #include <vector>
 
 #include "cmax_common.h"
@@ -582,20 +583,55 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
 // K2 + K2b in one pass for the gradient-magnitude cost: statistics as k_stats<GRADMAG>, and the UNSCALED
 // G' = (2 / n) / 8 * Sobel^T (gx, gy) 1_Omega  -- the chain factor of the objective (which needs the statistics of
 // every image) is applied by K3 when it loads its window (kFoldScale), and commutes with the blur transpose.
+constexpr int kGmTileH = 8, kGmTileW = 32;  // pixels per workgroup of k_stats_gimage_gm (256 threads, one pixel each)
 __global__ void __launch_bounds__(256)
 k_stats_gimage_gm(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot,
                   float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4, float *__restrict__ G) {
     __shared__ double smem[2 * 4];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned npix = (unsigned)H * (unsigned)W;
+    __shared__ float tile[kGmTileH + 4][kGmTileW + 4 + 1];  // image tile with a halo of 2 (zero outside the image)
+    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += nthreads) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tiles_w = (W + kGmTileW - 1) / kGmTileW;
+    const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
+    const int r0 = tr * kGmTileH - 2, c0 = tc * kGmTileW - 2;
+    for (int q = threadIdx.x; q < (kGmTileH + 4) * (kGmTileW + 4); q += 256) {
+        const int a = q / (kGmTileW + 4), b = q - a * (kGmTileW + 4);
+        const int r = r0 + a, c = c0 + b;
+        tile[a][b] = ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? img[(int64_t)r * W + c] : 0.f;
+    }
+    __syncthreads();
     const int i0 = omit ? 1 : 0;
     const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0);
+    const int la = threadIdx.x / kGmTileW, lb = threadIdx.x - la * kGmTileW;  // pixel of this thread inside the tile
+    const int i = r0 + 2 + la, j = c0 + 2 + lb;
     double v[2] = {0.0, 0.0};
-    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
-        const int r = (int)(p / (unsigned)W), c = (int)(p - (unsigned)r * (unsigned)W);
-        float gx, gy;
-        G[p] = gscale * sobel8_adj_f32(img, H, W, i0, r, c, &gx, &gy);
-        if (r >= i0 && r < H - i0 && c >= i0 && c < W - i0) v[0] += (double)(gx * gx + gy * gy);
+    if (i < H && j < W) {
+        // Sobel/8 responses of the 3x3 neighbourhood (the centre one also feeds the statistics)
+        float gx[3][3], gy[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float(*t)[kGmTileW + 4 + 1] = tile;
+                const int y = la + a, x = lb + b;  // top-left of the 3x3 window of output pixel (i + a - 1, j + b - 1)
+                gx[a][b] = ((t[y + 2][x] + 2.f * t[y + 2][x + 1] + t[y + 2][x + 2]) - (t[y][x] + 2.f * t[y][x + 1] + t[y][x + 2])) * 0.125f;
+                gy[a][b] = ((t[y][x + 2] + 2.f * t[y + 1][x + 2] + t[y + 2][x + 2]) - (t[y][x] + 2.f * t[y + 1][x] + t[y + 2][x])) * 0.125f;
+            }
+        // transpose: output pixel q = (i - a, j - b) reads this pixel with tap (a, b); q must lie in Omega
+        float s = 0.f;
+#pragma unroll
+        for (int a = -1; a <= 1; ++a)
+#pragma unroll
+            for (int b = -1; b <= 1; ++b) {
+                const int qi = i - a, qj = j - b;
+                if (qi < i0 || qi >= H - i0 || qj < i0 || qj >= W - i0) continue;
+                const float sx = (float)a * (b == 0 ? 2.f : 1.f);  // SX[a+1][b+1] = a * (2 - |b|)
+                const float sy = (float)b * (a == 0 ? 2.f : 1.f);  // SY[a+1][b+1] = b * (2 - |a|)
+                s += gx[1 - a][1 - b] * sx + gy[1 - a][1 - b] * sy;
+            }
+        const int64_t p = (int64_t)i * W + j;
+        G[p] = gscale * s;
+        if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) v[0] = (double)(gx[1][1] * gx[1][1] + gy[1][1] * gy[1][1]);
         if (zero_img) zero_img[p] = 0.f;
     }
     block_sum<2>(v, smem);
@@ -1378,10 +1414,11 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         if (fold == kFoldNone || fold == kFoldScale) {
             float *Gk = d->sigma > 0 ? h->Gt : h->G;
             if (fused_gm) {
+                const int gm_blocks = div_up(Hp, kGmTileH) * div_up(Wp, kGmTileW);  // one 8 x 32 pixel tile per workgroup
                 const bool clear_grad = k == 0 && grad_cleared_by_stats;
                 ProfScope prof(h, kProfStats, s);
                 for (int rep = 0; rep < h->prof_repeat; ++rep)
-                    hipLaunchKernelGGL(k_stats_gimage_gm, dim3(stat_blocks(h)), dim3(256), 0, s, h->last_iwe[k], Hp, Wp, d->omit_boundary, op.nsub,
+                    hipLaunchKernelGGL(k_stats_gimage_gm, dim3(gm_blocks), dim3(256), 0, s, h->last_iwe[k], Hp, Wp, d->omit_boundary, op.nsub,
                                        h->d_stat + k * kStatStride, zero_next ? zero_next + k * npix : nullptr,
                                        clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0, Gk);
             } else {
