@@ -114,6 +114,7 @@ SIGNATURES = {
     "cmax_sizeof_patch_objective": (c_int, []),
     "cmax_patch_plan_create": (c_int, [c_vp, ctypes.POINTER(CmaxPatchObjective), ctypes.POINTER(c_vp)]),
     "cmax_patch_plan_destroy": (c_int, [c_vp]),
+    "cmax_patch_plan_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cmax_patch_plan_evaluate": (c_int, [c_vp, c_vp, c_int, ctypes.POINTER(c_dbl), c_vp, c_vp]),
     "cmax_patch_plan_hvp": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

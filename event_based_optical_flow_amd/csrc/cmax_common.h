@@ -43,6 +43,21 @@ static inline int stream_grid(int64_t n, int block) {
     return (int)g;
 }
 
+// ---- library-internal view of the host-side state of a handle that changes from one evaluation to the next
+// (not exported: cmax_solver.hip replays captured hipGraphs and must advance this state the way the eager
+// launch sequence would have)
+struct HandleEvalState {
+    int cur_buf;
+    unsigned zero_mask[2];
+    int orig_valid, orig_cost, orig_omit;
+    double orig_sigma;
+    const float *last_iwe[4];
+    uint64_t generation;  // bumped whenever the packed events / work list (and with them device pointers) change
+    int profiling;
+};
+__attribute__((visibility("hidden"))) void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out);
+__attribute__((visibility("hidden"))) void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in);
+
 // ---- wave / block reductions (64-wide) -------------------------------------------------------
 // DPP on the VALU instead of ds_bpermute shuffles (~16 cycles each on gfx950): 4 row shifts, then lane 15 of
 // each row into the next row and lane 31 into rows 2-3; the sum of the wave ends up in LANE 63 only.

@@ -112,6 +112,7 @@ struct cmax_handle_s {
     float *hvp_img = nullptr;                 // [6, Hp, Wp] scratch of cmax_objective_hvp (allocated on first use)
     double *d_stat_tan = nullptr;             // [kStatStride] tangent statistics
     int64_t bytes = 0;
+    uint64_t generation = 0;  // bumped by set_events / set_time_bins (device pointers and the work list change)
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
     bool profiling = false;
     int prof_repeat = 1;  // > 1: every hot launch is issued this many times inside its event bracket (timing only)
@@ -1038,6 +1039,11 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
     const int max_groups = kAccCells / 256;
     const bool free_cut = h->n > (int64_t)1024 * kSegMax;
+    // batches far below one full segment per CU (the solver's 30k-event slices): a workgroup walks its events
+    // 8 (4) per thread, so 2040-event segments leave 15 workgroups with long serial work on a 256-CU chip.
+    // Cap the segment at n / 512 (>= 256 events): cfg1-shaped K3 13 -> 5 us.
+    int seg_cap = kSegMax;
+    if (h->n < (int64_t)256 * kSegMax) seg_cap = (int)std::min<int64_t>(kSegMax, std::max<int64_t>(256, (h->n + 511) / 512));
     std::vector<int4> segs;
     int begin = 0, count = 0, row_of_begin = -1, g0 = 0, g_last = 0;
     auto close = [&]() {
@@ -1048,10 +1054,10 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
         int b = group_start[g], c = group_start[g + 1] - group_start[g];
         const int trow = (g / T) / h->ntc;
         if (c == 0) continue;
-        if (count > 0 && (trow != row_of_begin || g - g0 + 1 > max_groups || (!free_cut && count + c > kSegMax))) close();
-        int limit = kSegMax;
-        if (!free_cut && c > kSegMax) {
-            const int parts = (c + kSegMax - 1) / kSegMax;
+        if (count > 0 && (trow != row_of_begin || g - g0 + 1 > max_groups || (!free_cut && count + c > seg_cap))) close();
+        int limit = seg_cap;
+        if (!free_cut && c > seg_cap) {
+            const int parts = (c + seg_cap - 1) / seg_cap;
             limit = (c + parts - 1) / parts;
         }
         while (c > 0) {
@@ -1117,6 +1123,30 @@ static int resort_events(cmax_handle_s *h, hipStream_t s) {
     std::swap(h->ry, h->ry_alt);
     std::swap(h->tau64, h->tau64_alt);
     return build_segments(h, T > 0 ? 1 : 256, s);
+}
+
+void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out) {
+    out->cur_buf = h->cur_buf;
+    out->zero_mask[0] = h->zero_mask[0];
+    out->zero_mask[1] = h->zero_mask[1];
+    out->orig_valid = h->orig_valid ? 1 : 0;
+    out->orig_cost = h->orig_cost;
+    out->orig_omit = h->orig_omit;
+    out->orig_sigma = h->orig_sigma;
+    for (int k = 0; k < 4; ++k) out->last_iwe[k] = h->last_iwe[k];
+    out->generation = h->generation;
+    out->profiling = h->profiling ? 1 : 0;
+}
+
+void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in) {
+    h->cur_buf = in->cur_buf;
+    h->zero_mask[0] = in->zero_mask[0];
+    h->zero_mask[1] = in->zero_mask[1];
+    h->orig_valid = in->orig_valid != 0;
+    h->orig_cost = in->orig_cost;
+    h->orig_omit = in->orig_omit;
+    h->orig_sigma = in->orig_sigma;
+    for (int k = 0; k < 4; ++k) h->last_iwe[k] = in->last_iwe[k];
 }
 
 }  // namespace cmax
@@ -1203,6 +1233,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     hipStream_t s = (hipStream_t)stream;
     h->orig_valid = false;
     h->n = 0;
+    ++h->generation;
     if (n > h->cap) {
         // the old buffers may still be in use by work queued on the stream
         CMAX_CHECK_HIP(hipStreamSynchronize(s));
@@ -1269,6 +1300,7 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     CMAX_REQUIRE(n_time_bin >= 0 && n_time_bin <= 255, "set_time_bins: n_time_bin must be in 0..255");
     if (n_time_bin == h->n_time_bin) return 0;
     h->n_time_bin = n_time_bin;
+    ++h->generation;
     if (h->n == 0) return 0;
     return resort_events(h, (hipStream_t)stream);
 }

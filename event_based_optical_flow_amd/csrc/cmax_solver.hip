@@ -14,15 +14,22 @@
 // path is fp32 per event with fp64 reductions as everywhere in cmax_fused.hip.
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "cmax_common.h"
+#include "cmax_image_kernels.h"
+#include "cmax_patch_kernels.h"
 
 namespace cmax {
 
+// out = in * scale [* *scale_dev]: scalars that change from call to call (the tangent's norm) live in device memory so
+// that a captured graph can be replayed with new values
 template <typename TO, typename TI>
-__global__ void __launch_bounds__(256) k_convert_scale(const TI *__restrict__ in, int64_t n, double scale, TO *__restrict__ out) {
+__global__ void __launch_bounds__(256)
+k_convert_scale(const TI *__restrict__ in, int64_t n, double scale, const double *__restrict__ scale_dev, TO *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (TO)((double)in[i] * scale);
+    const double sc = scale_dev ? scale * scale_dev[0] : scale;
+    if (i < n) out[i] = (TO)((double)in[i] * sc);
 }
 
 // acc (=, +=) w * g
@@ -33,21 +40,65 @@ __global__ void __launch_bounds__(256) k_accumulate(const float *__restrict__ g,
 
 struct FinalParams {
     int n_terms, with_tv, nx;
+    int ph, pw, tv_crop;       // patch grid of the total-variation term
     double weight[4], tv_weight, gscale;
 };
 
-// out[0] = loss, out[1 + j] = d loss / d x[j]
+// Tail of an evaluation in ONE workgroup (every dependent launch costs ~4.5 us on this chip and the operands are a
+// few hundred numbers): total variation of the patch motion x [2,ph,pw] -- mean |Sobel/8| over 4 channels,
+// TotalVariation.calculate_torch, src/costs/total_variation.py:60-75, 110-126 -- and its sub-gradient, the weighted
+// sum of the contrast terms, and the chain through t_scale:
+//   out[0] = sum_i w_i result_i + w_tv TV(x),   out[1 + j] = gscale * gx[j] + w_tv dTV/dx[j]
+// gx comes as fp64 (gx64) or fp32 (gx32); gscale_dev multiplies gscale (Hessian-vector products).  `out` may be
+// pinned host memory.
 __global__ void __launch_bounds__(256)
-k_patch_final(FinalParams fp, const double *__restrict__ results, const double *__restrict__ tv_value, const double *__restrict__ gx,
-              const double *__restrict__ gtv, double *__restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) {
+k_patch_tail(FinalParams fp, const double *__restrict__ results, const double *__restrict__ x, const double *__restrict__ gx64,
+             const float *__restrict__ gx32, const double *__restrict__ gscale_dev, double *__restrict__ out) {
+    __shared__ double smem[4];
+    __shared__ double s_tv;
+    const int h = fp.ph, w = fp.pw, hw = h * w;
+    const int i0 = fp.tv_crop ? 1 : 0, hh = h - 2 * i0, ww = w - 2 * i0;
+    const double ntv = 4.0 * (double)hh * (double)ww;
+    if (fp.with_tv) {
+        double v[1] = {0.0};
+        for (int q = threadIdx.x; q < 2 * hh * ww; q += blockDim.x) {
+            const int c = q / (hh * ww), r = q - c * hh * ww;
+            double sx, sy;
+            sobel8<double>(x + c * hw, h, w, r / ww + i0, r % ww + i0, sx, sy);
+            v[0] += fabs(sx) + fabs(sy);
+        }
+        block_sum<1>(v, smem);
+        if (threadIdx.x == 0) s_tv = v[0] / ntv;
+        __syncthreads();
+    }
+    double gscale = fp.gscale;
+    if (gscale_dev) gscale *= gscale_dev[0];
+    if (threadIdx.x == 0) {
         double loss = 0.0;
         for (int i = 0; i < fp.n_terms; ++i) loss += fp.weight[i] * results[8 * i];
-        if (fp.with_tv) loss += fp.tv_weight * tv_value[0];
+        if (fp.with_tv) loss += fp.tv_weight * s_tv;
         out[0] = loss;
     }
-    if (j < fp.nx) out[1 + j] = fp.gscale * gx[j] + (fp.with_tv ? gtv[j] : 0.0);
+    for (int p = threadIdx.x; p < fp.nx; p += blockDim.x) {
+        double g = gscale * (gx64 ? gx64[p] : (double)gx32[p]);
+        if (fp.with_tv) {
+            const int c = p / hw, r = p - c * hw, i = r / w, j = r % w;
+            const double *f = x + c * hw;
+            const double SX[3][3] = {{-1, -2, -1}, {0, 0, 0}, {1, 2, 1}};
+            const double SY[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}};
+            double sgn = 0.0;
+            for (int a = -1; a <= 1; ++a)
+                for (int b = -1; b <= 1; ++b) {
+                    const int qi = i - a, qj = j - b;  // output pixel that reads (i, j) with tap (a, b)
+                    if (qi < i0 || qi >= h - i0 || qj < i0 || qj >= w - i0) continue;
+                    double sx, sy;
+                    sobel8<double>(f, h, w, qi, qj, sx, sy);
+                    sgn += (double)((sx > 0) - (sx < 0)) * SX[a + 1][b + 1] + (double)((sy > 0) - (sy < 0)) * SY[a + 1][b + 1];
+                }
+            g += fp.tv_weight * sgn / 8.0 / ntv;
+        }
+        out[1 + p] = g;
+    }
 }
 
 }  // namespace cmax
@@ -60,8 +111,24 @@ struct cmax_patch_plan_s {
     int64_t nmotion = 0;   // nflow or T * nflow
     double *x64 = nullptr, *v64 = nullptr, *flow64 = nullptr, *vox64 = nullptr, *gacc64 = nullptr, *gflow64 = nullptr;
     double *gx64 = nullptr, *gtv64 = nullptr, *tv_value = nullptr, *results = nullptr, *out64 = nullptr, *d_tvw = nullptr;
-    float *motion32 = nullptr, *grad32 = nullptr, *tan32 = nullptr;
-    double *h_in = nullptr, *h_out = nullptr;  // pinned staging: x | v, loss | grad
+    float *motion32 = nullptr, *grad32 = nullptr, *tan32 = nullptr, *gx32 = nullptr;
+    double *h_out_dev = nullptr;  // device view of the pinned output: the tail kernel writes the result there
+    double *h_in = nullptr, *h_out = nullptr;  // pinned staging: x | v | 2 scalars, loss | grad
+    // Captured launch sequences (hipGraph), replayed on the plan's own stream: an evaluation is ~25 small launches,
+    // host-bound when issued one by one.  Keyed by everything that changes the sequence: the kind of call and the
+    // handle's host-side state (which vote buffer is current, which images are already zero, whether the
+    // un-warped image is cached, the generation of the packed events).
+    struct GraphEntry {
+        uint64_t key;
+        uint64_t generation;
+        hipGraphExec_t exec;
+        cmax::HandleEvalState post;  // handle state after the sequence
+    };
+    std::vector<GraphEntry> graphs;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_caller = nullptr;
+    bool graphs_ok = true;
+    int eager_calls = 0;  // the first calls run eagerly (lazy allocations, caches)
 };
 
 using namespace cmax;
@@ -80,23 +147,214 @@ int plan_alloc(T **p, int64_t count) {
 
 // x (host) -> fp32 motion of the fused objective: flow [2,H,W] or voxel [T,2,H,W] in pixel per normalised time.
 // Leaves the fp64 flow (scaled) in flow64 and, when time-aware, the fp64 voxel in vox64.
-int forward_motion(cmax_patch_plan_s *p, const double *src64, double scale, float *dst32, hipStream_t s) {
+int forward_motion(cmax_patch_plan_s *p, const double *src64, double scale, const double *scale_dev, float *dst32, hipStream_t s) {
     const cmax_patch_objective_t &d = p->d;
-    int rc = cmax_patch_to_dense(src64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 0, p->flow64, s);
-    if (rc) return rc;
     const int grid = div_up(p->nflow, 256);
-    if (!d.time_aware) {
-        hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(grid), dim3(256), 0, s, p->flow64, p->nflow, scale, dst32);
+    if (!d.time_aware && !scale_dev) {  // patch grid -> fp32 flow * scale in one kernel
+        hipLaunchKernelGGL((k_patch_to_dense<double, float>), dim3(grid), dim3(256), 0, s, src64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w,
+                           d.H, d.W, dst32, scale);
         CMAX_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL((k_convert_scale<double, double>), dim3(grid), dim3(256), 0, s, p->flow64, p->nflow, scale, p->flow64);
+    int rc = cmax_patch_to_dense(src64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 0, p->flow64, s);
+    if (rc) return rc;
+    if (!d.time_aware) {
+        hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(grid), dim3(256), 0, s, p->flow64, p->nflow, scale, scale_dev, dst32);
+        CMAX_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL((k_convert_scale<double, double>), dim3(grid), dim3(256), 0, s, p->flow64, p->nflow, scale, scale_dev, p->flow64);
     CMAX_CHECK_LAUNCH();
     // the voxel is built on the displacement field (patch_contrast_pyramid.py:452, 499-515)
     rc = cmax_voxel_construct(p->flow64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->vox64, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->vox64, p->nmotion, 1.0, dst32);
+    hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->vox64, p->nmotion, 1.0, (const double *)nullptr, dst32);
     CMAX_CHECK_LAUNCH();
+    return 0;
+}
+
+// gradient of the fused terms w.r.t. the patch motion (without t_scale): gx64 or gx32 (returned through the pointers)
+int backward_motion(cmax_patch_plan_s *p, const double **gx64, const float **gx32, double *weight_scale, hipStream_t s) {
+    const cmax_patch_objective_t &d = p->d;
+    *gx64 = nullptr;
+    *gx32 = nullptr;
+    *weight_scale = 1.0;
+    if (d.n_terms == 1 && !d.time_aware) {
+        // one term on the dense flow: the adjoint of the interpolation reads the fp32 flow gradient as it is
+        // (fp64 accumulation inside), the term's weight is applied by the tail
+        int rc = cmax_patch_to_dense(p->grad32, CMAX_F32, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx32, s);
+        if (rc) return rc;
+        *gx32 = p->gx32;
+        *weight_scale = d.weight[0];
+        return 0;
+    }
+    const double *gflow = p->gacc64;
+    if (d.time_aware) {
+        int rc = cmax_voxel_construct_adj(p->vox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->gflow64, s);
+        if (rc) return rc;
+        gflow = p->gflow64;
+    }
+    int rc = cmax_patch_to_dense(gflow, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
+    if (rc) return rc;
+    *gx64 = p->gx64;
+    return 0;
+}
+
+// Everything between the pinned input and the pinned output of one evaluation, enqueued on `s` (no synchronisation).
+int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t s) {
+    const cmax_patch_objective_t &d = p->d;
+    CMAX_CHECK_HIP(hipMemcpyAsync(p->x64, p->h_in, (size_t)p->nx * sizeof(double), hipMemcpyHostToDevice, s));
+    int rc = forward_motion(p, p->x64, d.t_scale, nullptr, p->motion32, s);
+    if (rc) return rc;
+    const bool accumulate = want_grad && !(d.n_terms == 1 && !d.time_aware);
+    for (int i = 0; i < d.n_terms; ++i) {
+        rc = cmax_objective(p->handle, &d.term[i], p->motion32, p->results + 8 * i, want_grad ? p->grad32 : nullptr, s);
+        if (rc) return rc;
+        if (accumulate) {
+            hipLaunchKernelGGL(k_accumulate, dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64);
+            CMAX_CHECK_LAUNCH();
+        }
+    }
+    const double *gx64 = nullptr;
+    const float *gx32 = nullptr;
+    double wscale = 1.0;
+    if (want_grad) {
+        rc = backward_motion(p, &gx64, &gx32, &wscale, s);
+        if (rc) return rc;
+    }
+    FinalParams fp;
+    fp.n_terms = d.n_terms;
+    fp.with_tv = tv ? 1 : 0;
+    fp.nx = want_grad ? p->nx : 0;
+    fp.ph = d.ph;
+    fp.pw = d.pw;
+    fp.tv_crop = d.tv_omit_boundary && d.ph > 2 && d.pw > 2;  // total_variation.py:123-125
+    for (int i = 0; i < 4; ++i) fp.weight[i] = d.weight[i];
+    fp.tv_weight = d.tv_weight;
+    fp.gscale = d.t_scale * wscale;  // d(flow * t_scale) / d flow
+    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, gx64, gx32, (const double *)nullptr, p->h_out_dev);
+    CMAX_CHECK_LAUNCH();
+    return 0;
+}
+
+// Hessian-vector product: h_in = x | v | 1/|v|_inf | |v|_inf
+int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
+    const cmax_patch_objective_t &d = p->d;
+    // x64 | v64 | scal64 are one allocation: a single copy brings x, v and the two scalars
+    CMAX_CHECK_HIP(hipMemcpyAsync(p->x64, p->h_in, (2 * (size_t)p->nx + 2) * sizeof(double), hipMemcpyHostToDevice, s));
+    const double *inv_vmax = p->x64 + 2 * p->nx, *vmax = inv_vmax + 1;
+    int rc = forward_motion(p, p->x64, d.t_scale, nullptr, p->motion32, s);
+    if (rc) return rc;
+    // tangent of the flow, scaled to max-norm <= 1 (the interpolation is a negated convex combination, so
+    // |P v|_inf <= |v|_inf): u = (t_scale * |v|_inf) * tan32, and H is linear in u
+    rc = forward_motion(p, p->v64, 1.0, inv_vmax, p->tan32, s);
+    if (rc) return rc;
+    const bool accumulate = !(d.n_terms == 1 && !d.time_aware);
+    for (int i = 0; i < d.n_terms; ++i) {
+        rc = cmax_objective_hvp(p->handle, &d.term[i], p->motion32, p->tan32, p->grad32, s);
+        if (rc) return rc;
+        if (accumulate) {
+            hipLaunchKernelGGL(k_accumulate, dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64);
+            CMAX_CHECK_LAUNCH();
+        }
+    }
+    const double *gx64 = nullptr;
+    const float *gx32 = nullptr;
+    double wscale = 1.0;
+    rc = backward_motion(p, &gx64, &gx32, &wscale, s);
+    if (rc) return rc;
+    FinalParams fp;
+    fp.n_terms = 0;
+    fp.with_tv = 0;  // total_variation is piecewise linear: zero Hessian almost everywhere
+    fp.nx = p->nx;
+    fp.ph = d.ph;
+    fp.pw = d.pw;
+    fp.tv_crop = 0;
+    for (int i = 0; i < 4; ++i) fp.weight[i] = 0.0;
+    fp.tv_weight = 0.0;
+    fp.gscale = d.t_scale * d.t_scale * wscale;  // H_x = t^2 P^T H_flow P (times |v|_inf, from device memory)
+    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, gx64, gx32, vmax, p->h_out_dev);
+    CMAX_CHECK_LAUNCH();
+    return 0;
+}
+
+uint64_t state_key(const HandleEvalState &st, int kind) {
+    uint64_t sb;
+    std::memcpy(&sb, &st.orig_sigma, sizeof(sb));
+    uint64_t k = (uint64_t)kind;
+    k = k * 1000003u + (uint64_t)st.cur_buf;
+    k = k * 1000003u + st.zero_mask[0];
+    k = k * 1000003u + st.zero_mask[1];
+    k = k * 1000003u + (uint64_t)st.orig_valid;
+    k = k * 1000003u + (uint64_t)(st.orig_cost + 7);
+    k = k * 1000003u + (uint64_t)(st.orig_omit + 7);
+    k = k * 1000003u + sb;
+    return k;
+}
+
+void drop_graphs(cmax_patch_plan_s *p) {
+    for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
+    p->graphs.clear();
+}
+
+// Runs `enqueue(stream)` and waits for its result: eagerly on the caller's stream for the first calls (and whenever
+// the handle is being profiled or a capture failed), afterwards as a captured hipGraph replayed on the plan's stream.
+template <typename F>
+int run_sequence(cmax_patch_plan_s *p, int kind, hipStream_t caller, F enqueue) {
+    HandleEvalState pre;
+    handle_get_eval_state(p->handle, &pre);
+    if (!p->graphs.empty() && p->graphs[0].generation != pre.generation) {
+        drop_graphs(p);  // new events behind the handle: other device pointers, another work list
+        p->eager_calls = 0;
+    }
+    const bool eager = !p->graphs_ok || pre.profiling || p->eager_calls < 3;
+    if (eager) {
+        ++p->eager_calls;
+        int rc = enqueue(caller);
+        if (rc) return rc;
+        CMAX_CHECK_HIP(hipStreamSynchronize(caller));
+        return 0;
+    }
+    const uint64_t key = state_key(pre, kind);
+    cmax_patch_plan_s::GraphEntry *entry = nullptr;
+    for (auto &g : p->graphs)
+        if (g.key == key) entry = &g;
+    if (!entry) {
+        if (p->graphs.size() >= 32) drop_graphs(p);
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(p->own_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        int rc = 0;
+        if (ok) {
+            rc = enqueue(p->own_stream);  // host-side bookkeeping of the handle runs as in an eager call
+            ok = hipStreamEndCapture(p->own_stream, &graph) == hipSuccess && rc == 0 && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {  // never again: fall back to eager launches
+            (void)hipGetLastError();
+            p->graphs_ok = false;
+            handle_set_eval_state(p->handle, &pre);
+            rc = enqueue(caller);
+            if (rc) return rc;
+            CMAX_CHECK_HIP(hipStreamSynchronize(caller));
+            return 0;
+        }
+        cmax_patch_plan_s::GraphEntry e;
+        e.key = key;
+        e.generation = pre.generation;
+        e.exec = exec;
+        handle_get_eval_state(p->handle, &e.post);
+        p->graphs.push_back(e);
+        entry = &p->graphs.back();
+    } else {
+        handle_set_eval_state(p->handle, &entry->post);
+    }
+    // order after whatever the caller has queued, run, wait
+    CMAX_CHECK_HIP(hipEventRecord(p->ev_caller, caller));
+    CMAX_CHECK_HIP(hipStreamWaitEvent(p->own_stream, p->ev_caller, 0));
+    CMAX_CHECK_HIP(hipGraphLaunch(entry->exec, p->own_stream));
+    CMAX_CHECK_HIP(hipStreamSynchronize(p->own_stream));
     return 0;
 }
 
@@ -127,8 +385,8 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     p->nflow = 2 * (int64_t)d.H * d.W;
     p->nmotion = d.time_aware ? (int64_t)d.T * p->nflow : p->nflow;
     int rc = 0;
-    if (!rc) rc = plan_alloc(&p->x64, p->nx);
-    if (!rc) rc = plan_alloc(&p->v64, p->nx);
+    if (!rc) rc = plan_alloc(&p->x64, 2 * (int64_t)p->nx + 2);  // x | v | 2 scalars, filled by one copy
+    if (!rc) p->v64 = p->x64 + p->nx;
     if (!rc) rc = plan_alloc(&p->flow64, p->nflow);
     if (!rc && d.time_aware) rc = plan_alloc(&p->vox64, p->nmotion);
     if (!rc) rc = plan_alloc(&p->gacc64, p->nmotion);
@@ -142,8 +400,15 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     if (!rc) rc = plan_alloc(&p->motion32, p->nmotion);
     if (!rc) rc = plan_alloc(&p->grad32, p->nmotion);
     if (!rc) rc = plan_alloc(&p->tan32, p->nmotion);
-    if (!rc && hipHostMalloc((void **)&p->h_in, 2 * (size_t)p->nx * sizeof(double)) != hipSuccess) rc = CMAX_ENOMEM;
-    if (!rc && hipHostMalloc((void **)&p->h_out, (1 + (size_t)p->nx) * sizeof(double)) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc) rc = plan_alloc(&p->gx32, p->nx);
+    if (!rc && hipHostMalloc((void **)&p->h_in, (2 * (size_t)p->nx + 2) * sizeof(double)) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc && hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc && hipEventCreateWithFlags(&p->ev_caller, hipEventDisableTiming) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc && hipHostMalloc((void **)&p->h_out, (1 + (size_t)p->nx) * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc && hipHostGetDevicePointer((void **)&p->h_out_dev, p->h_out, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        p->h_out_dev = p->h_out;  // unified addressing: pinned host memory is addressable from the device as it is
+    }
     if (!rc && hipMemcpy(p->d_tvw, &d.tv_weight, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = CMAX_ENOMEM;
     if (rc) {
         if (rc == CMAX_ENOMEM) set_error("patch_plan_create: allocation failed");
@@ -154,12 +419,22 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     return 0;
 }
 
+int cmax_patch_plan_info(cmax_patch_plan_t p, int *n_graphs, int *graph_replay_enabled) {
+    CMAX_REQUIRE(p && n_graphs && graph_replay_enabled, "patch_plan_info");
+    *n_graphs = (int)p->graphs.size();
+    *graph_replay_enabled = p->graphs_ok ? 1 : 0;
+    return 0;
+}
+
 int cmax_patch_plan_destroy(cmax_patch_plan_t p) {
     if (!p) return 0;
-    double *d64[] = {p->x64, p->v64, p->flow64, p->vox64, p->gacc64, p->gflow64, p->gx64, p->gtv64, p->tv_value, p->results, p->out64, p->d_tvw};
+    drop_graphs(p);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->ev_caller) (void)hipEventDestroy(p->ev_caller);
+    double *d64[] = {p->x64, p->flow64, p->vox64, p->gacc64, p->gflow64, p->gx64, p->gtv64, p->tv_value, p->results, p->out64, p->d_tvw};
     for (double *q : d64)
         if (q) (void)hipFree(q);
-    float *d32[] = {p->motion32, p->grad32, p->tan32};
+    float *d32[] = {p->motion32, p->grad32, p->tan32, p->gx32};
     for (float *q : d32)
         if (q) (void)hipFree(q);
     if (p->h_in) (void)hipHostFree(p->h_in);
@@ -171,47 +446,11 @@ int cmax_patch_plan_destroy(cmax_patch_plan_t p) {
 int cmax_patch_plan_evaluate(cmax_patch_plan_t p, const double *x_host, int with_tv, double *loss_host, double *grad_host,
                              cmax_stream_t stream) {
     CMAX_REQUIRE(p && x_host && loss_host, "patch_plan_evaluate: null pointer");
-    const cmax_patch_objective_t &d = p->d;
-    hipStream_t s = (hipStream_t)stream;
-    const bool tv = with_tv && d.tv_weight != 0.0;
+    const bool tv = with_tv && p->d.tv_weight != 0.0;
     std::memcpy(p->h_in, x_host, (size_t)p->nx * sizeof(double));
-    CMAX_CHECK_HIP(hipMemcpyAsync(p->x64, p->h_in, (size_t)p->nx * sizeof(double), hipMemcpyHostToDevice, s));
-    int rc = forward_motion(p, p->x64, d.t_scale, p->motion32, s);
+    const int kind = (tv ? 1 : 0) | (grad_host ? 2 : 0);
+    int rc = run_sequence(p, kind, (hipStream_t)stream, [&](hipStream_t s) { return enqueue_evaluate(p, tv, grad_host != nullptr, s); });
     if (rc) return rc;
-    for (int i = 0; i < d.n_terms; ++i) {
-        rc = cmax_objective(p->handle, &d.term[i], p->motion32, p->results + 8 * i, grad_host ? p->grad32 : nullptr, s);
-        if (rc) return rc;
-        if (grad_host) {
-            hipLaunchKernelGGL(k_accumulate, dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64);
-            CMAX_CHECK_LAUNCH();
-        }
-    }
-    if (grad_host) {
-        const double *gflow = p->gacc64;
-        if (d.time_aware) {
-            rc = cmax_voxel_construct_adj(p->vox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->gflow64, s);
-            if (rc) return rc;
-            gflow = p->gflow64;
-        }
-        rc = cmax_patch_to_dense(gflow, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
-        if (rc) return rc;
-    }
-    if (tv) {
-        rc = cmax_total_variation(p->x64, CMAX_F64, d.ph, d.pw, d.tv_omit_boundary, p->tv_value, grad_host ? p->gtv64 : nullptr, p->d_tvw, s);
-        if (rc) return rc;
-    }
-    FinalParams fp;
-    fp.n_terms = d.n_terms;
-    fp.with_tv = tv ? 1 : 0;
-    fp.nx = grad_host ? p->nx : 0;
-    for (int i = 0; i < 4; ++i) fp.weight[i] = d.weight[i];
-    fp.tv_weight = d.tv_weight;
-    fp.gscale = d.t_scale;  // d(flow * t_scale) / d flow
-    hipLaunchKernelGGL(k_patch_final, dim3(div_up(p->nx + 1, 256)), dim3(256), 0, s, fp, p->results, p->tv_value, p->gx64, p->gtv64, p->out64);
-    CMAX_CHECK_LAUNCH();
-    const size_t nout = grad_host ? 1 + (size_t)p->nx : 1;
-    CMAX_CHECK_HIP(hipMemcpyAsync(p->h_out, p->out64, nout * sizeof(double), hipMemcpyDeviceToHost, s));
-    CMAX_CHECK_HIP(hipStreamSynchronize(s));
     *loss_host = p->h_out[0];
     if (grad_host) std::memcpy(grad_host, p->h_out + 1, (size_t)p->nx * sizeof(double));
     return 0;
@@ -221,7 +460,6 @@ int cmax_patch_plan_hvp(cmax_patch_plan_t p, const double *x_host, const double 
     CMAX_REQUIRE(p && x_host && v_host && hv_host, "patch_plan_hvp: null pointer");
     const cmax_patch_objective_t &d = p->d;
     CMAX_REQUIRE(!d.time_aware, "patch_plan_hvp: the Burgers voxel chain has no second-order adjoint (difference the gradient instead)");
-    hipStream_t s = (hipStream_t)stream;
     double vmax = 0.0;
     for (int j = 0; j < p->nx; ++j) vmax = fabs(v_host[j]) > vmax ? fabs(v_host[j]) : vmax;
     if (!(vmax > 0.0)) {
@@ -230,33 +468,10 @@ int cmax_patch_plan_hvp(cmax_patch_plan_t p, const double *x_host, const double 
     }
     std::memcpy(p->h_in, x_host, (size_t)p->nx * sizeof(double));
     std::memcpy(p->h_in + p->nx, v_host, (size_t)p->nx * sizeof(double));
-    CMAX_CHECK_HIP(hipMemcpyAsync(p->x64, p->h_in, (size_t)p->nx * sizeof(double), hipMemcpyHostToDevice, s));
-    CMAX_CHECK_HIP(hipMemcpyAsync(p->v64, p->h_in + p->nx, (size_t)p->nx * sizeof(double), hipMemcpyHostToDevice, s));
-    int rc = forward_motion(p, p->x64, d.t_scale, p->motion32, s);
+    p->h_in[2 * p->nx] = 1.0 / vmax;  // the tangent of the flow is scaled to max-norm <= 1 ...
+    p->h_in[2 * p->nx + 1] = vmax;    // ... and the product scaled back (H is linear in the tangent)
+    int rc = run_sequence(p, 4, (hipStream_t)stream, [&](hipStream_t s) { return enqueue_hvp(p, s); });
     if (rc) return rc;
-    // tangent of the flow, scaled to max-norm <= 1 (the interpolation is a negated convex combination, so
-    // |P v|_inf <= |v|_inf): u = (t_scale * vmax) * tan32, and H is linear in u
-    rc = forward_motion(p, p->v64, 1.0 / vmax, p->tan32, s);
-    if (rc) return rc;
-    for (int i = 0; i < d.n_terms; ++i) {
-        rc = cmax_objective_hvp(p->handle, &d.term[i], p->motion32, p->tan32, p->grad32, s);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_accumulate, dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64);
-        CMAX_CHECK_LAUNCH();
-    }
-    rc = cmax_patch_to_dense(p->gacc64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
-    if (rc) return rc;
-    FinalParams fp;
-    fp.n_terms = 0;
-    fp.with_tv = 0;  // total_variation is piecewise linear: zero Hessian almost everywhere
-    fp.nx = p->nx;
-    for (int i = 0; i < 4; ++i) fp.weight[i] = 0.0;
-    fp.tv_weight = 0.0;
-    fp.gscale = d.t_scale * d.t_scale * vmax;  // H_x = t^2 P^T H_flow P
-    hipLaunchKernelGGL(k_patch_final, dim3(div_up(p->nx + 1, 256)), dim3(256), 0, s, fp, p->results, p->tv_value, p->gx64, p->gtv64, p->out64);
-    CMAX_CHECK_LAUNCH();
-    CMAX_CHECK_HIP(hipMemcpyAsync(p->h_out, p->out64, (1 + (size_t)p->nx) * sizeof(double), hipMemcpyDeviceToHost, s));
-    CMAX_CHECK_HIP(hipStreamSynchronize(s));
     std::memcpy(hv_host, p->h_out + 1, (size_t)p->nx * sizeof(double));
     return 0;
 }

@@ -87,6 +87,12 @@ class PatchFlowObjective:
             except Exception:  # interpreter shutdown
                 pass
 
+    def native_plan_info(self):
+        """(number of captured hipGraphs, graph replay enabled) of the native plan."""
+        n, ok = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.load().cmax_patch_plan_info(self._plan, ctypes.byref(n), ctypes.byref(ok)))
+        return n.value, bool(ok.value)
+
     @property
     def has_native_plan(self) -> bool:
         """TorchWrapper calls `value_and_grad_numpy` / `hvp_numpy` when this is True."""
