@@ -51,23 +51,42 @@ struct FinalParams {
 //   out[0] = sum_i w_i result_i + w_tv TV(x),   out[1 + j] = gscale * gx[j] + w_tv dTV/dx[j]
 // gx comes as fp64 (gx64) or fp32 (gx32); gscale_dev multiplies gscale (Hessian-vector products).  `out` may be
 // pinned host memory.
+constexpr int kTailLds = 4096;  // patch-grid values staged in LDS by k_patch_tail (2 x 45 x 45 patches)
 __global__ void __launch_bounds__(256)
 k_patch_tail(FinalParams fp, const double *__restrict__ results, const double *__restrict__ x, const double *__restrict__ gx64,
              const float *__restrict__ gx32, const double *__restrict__ gscale_dev, double *__restrict__ out) {
     __shared__ double smem[4];
     __shared__ double s_tv;
+    __shared__ double s_x[kTailLds];
+    __shared__ signed char s_sx[kTailLds], s_sy[kTailLds];  // sign of the Sobel responses on Omega, 0 elsewhere
     const int h = fp.ph, w = fp.pw, hw = h * w;
     const int i0 = fp.tv_crop ? 1 : 0, hh = h - 2 * i0, ww = w - 2 * i0;
     const double ntv = 4.0 * (double)hh * (double)ww;
+    const bool lds = 2 * hw <= kTailLds;
+    const double *xs = x;
     if (fp.with_tv) {
-        double v[1] = {0.0};
-        for (int q = threadIdx.x; q < 2 * hh * ww; q += blockDim.x) {
-            const int c = q / (hh * ww), r = q - c * hh * ww;
-            double sx, sy;
-            sobel8<double>(x + c * hw, h, w, r / ww + i0, r % ww + i0, sx, sy);
-            v[0] += fabs(sx) + fabs(sy);
+        if (lds) {
+            for (int p = threadIdx.x; p < 2 * hw; p += blockDim.x) s_x[p] = x[p];
+            __syncthreads();
+            xs = s_x;
         }
-        block_sum<1>(v, smem);
+        double v[1] = {0.0};
+        for (int p = threadIdx.x; p < 2 * hw; p += blockDim.x) {
+            const int c = p / hw, r = p - c * hw, i = r / w, j = r - i * w;
+            signed char gx = 0, gy = 0;
+            if (i >= i0 && i < h - i0 && j >= i0 && j < w - i0) {
+                double sx, sy;
+                sobel8<double>(xs + c * hw, h, w, i, j, sx, sy);
+                v[0] += fabs(sx) + fabs(sy);
+                gx = (signed char)((sx > 0) - (sx < 0));
+                gy = (signed char)((sy > 0) - (sy < 0));
+            }
+            if (lds) {
+                s_sx[p] = gx;
+                s_sy[p] = gy;
+            }
+        }
+        block_sum<1>(v, smem);  // its barriers also publish s_sx / s_sy
         if (threadIdx.x == 0) s_tv = v[0] / ntv;
         __syncthreads();
     }
@@ -82,18 +101,24 @@ k_patch_tail(FinalParams fp, const double *__restrict__ results, const double *_
     for (int p = threadIdx.x; p < fp.nx; p += blockDim.x) {
         double g = gscale * (gx64 ? gx64[p] : (double)gx32[p]);
         if (fp.with_tv) {
-            const int c = p / hw, r = p - c * hw, i = r / w, j = r % w;
-            const double *f = x + c * hw;
-            const double SX[3][3] = {{-1, -2, -1}, {0, 0, 0}, {1, 2, 1}};
-            const double SY[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}};
+            const int c = p / hw, r = p - c * hw, i = r / w, j = r - i * w;
             double sgn = 0.0;
             for (int a = -1; a <= 1; ++a)
                 for (int b = -1; b <= 1; ++b) {
                     const int qi = i - a, qj = j - b;  // output pixel that reads (i, j) with tap (a, b)
                     if (qi < i0 || qi >= h - i0 || qj < i0 || qj >= w - i0) continue;
-                    double sx, sy;
-                    sobel8<double>(f, h, w, qi, qj, sx, sy);
-                    sgn += (double)((sx > 0) - (sx < 0)) * SX[a + 1][b + 1] + (double)((sy > 0) - (sy < 0)) * SY[a + 1][b + 1];
+                    double gsx, gsy;
+                    if (lds) {
+                        gsx = (double)s_sx[c * hw + qi * w + qj];
+                        gsy = (double)s_sy[c * hw + qi * w + qj];
+                    } else {
+                        double sx, sy;
+                        sobel8<double>(x + c * hw, h, w, qi, qj, sx, sy);
+                        gsx = (double)((sx > 0) - (sx < 0));
+                        gsy = (double)((sy > 0) - (sy < 0));
+                    }
+                    // SX[a+1][b+1] = a * (2 - |b|), SY[a+1][b+1] = b * (2 - |a|)
+                    sgn += gsx * (double)(a * (2 - (b < 0 ? -b : b))) + gsy * (double)(b * (2 - (a < 0 ? -a : a)));
                 }
             g += fp.tv_weight * sgn / 8.0 / ntv;
         }
