@@ -584,6 +584,37 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
 // K2 + K2b in one pass for the gradient-magnitude cost: statistics as k_stats<GRADMAG>, and the UNSCALED
 // G' = (2 / n) / 8 * Sobel^T (gx, gy) 1_Omega  -- the chain factor of the objective (which needs the statistics of
 // every image) is applied by K3 when it loads its window (kFoldScale), and commutes with the blur transpose.
+// Blurred variance cost in two image kernels instead of four (every dependent launch costs ~4.5 us):
+//   k_blur_stats_var      Ib = blur3(I) (written: K3 / cmax_copy_iwe read it), sum Ib, sum Ib^2 over Omega, zeroing
+//   k_gimage_blur_adj_var G = blur3^T [ c (Ib - mu) 1_Omega ]  with c, mu from the finished statistics
+__global__ void __launch_bounds__(256)
+k_blur_stats_var(const float *__restrict__ img, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_slot,
+                 float *__restrict__ blurred, float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4) {
+    __shared__ double smem[2 * 4];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned npix = (unsigned)H * (unsigned)W;
+    const int i0 = omit ? 1 : 0;
+    double v[2] = {0.0, 0.0};
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+        const int i = (int)(p / (unsigned)W), j = (int)(p - (unsigned)i * (unsigned)W);
+        const int im = refl101(i - 1, H), ip = refl101(i + 1, H), jm = refl101(j - 1, W), jp = refl101(j + 1, W);
+        auto row = [&](int r) { return k1 * img[(int64_t)r * W + jm] + k0 * img[(int64_t)r * W + j] + k1 * img[(int64_t)r * W + jp]; };
+        const float b = k1 * row(im) + k0 * row(i) + k1 * row(ip);  // same arithmetic as k_blur3
+        blurred[p] = b;
+        if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) {
+            v[0] += (double)b;
+            v[1] += (double)b * (double)b;
+        }
+        if (zero_img) zero_img[p] = 0.f;
+    }
+    block_sum<2>(v, smem);
+    if (threadIdx.x == 0) {
+        double *a = stat_slot + 2 * (blockIdx.x % nsub);
+        atomic_add(&a[0], v[0]);
+        atomic_add(&a[1], v[1]);
+    }
+}
+
 constexpr int kGmTileH = 8, kGmTileW = 32;  // pixels per workgroup of k_stats_gimage_gm (256 threads, one pixel each)
 __global__ void __launch_bounds__(256)
 k_stats_gimage_gm(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot,
@@ -662,6 +693,23 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
     } else {
         G[p] = (float)(coef * (2.0 / npix) / 8.0) * sobel8_adj_f32(img, H, W, i0, i, j);
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_gimage_blur_adj_var(const float *__restrict__ blurred, ObjParams op, int k, const double *__restrict__ stat, float k0, float k1,
+                      float *__restrict__ G) {
+    const int H = op.H, W = op.W, i0 = op.omit ? 1 : 0;
+    double mud = 0.0;
+    const double coef = chain_coef<true>(op, stat, k, &mud);  // every wave is converged here
+    const float c2 = (float)(coef * 2.0 / (region_pixels(H, W, op.omit) - 1.0)), mu = (float)mud;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int i = (int)(p / W), j = (int)(p % W);
+    auto g = [&](int r, int c) -> float {  // dL/d(blurred image): what k_gimage<VARIANCE> writes
+        const bool in = (r >= i0) && (r < H - i0) && (c >= i0) && (c < W - i0);
+        return in ? c2 * (blurred[(int64_t)r * W + c] - mu) : 0.f;
+    };
+    G[p] = blur_adj_1d<float>(i, H, k0, k1, [&](int r) { return blur_adj_1d<float>(j, W, k0, k1, [&](int c) { return g(r, c); }); });
 }
 
 // =============================================================================================
@@ -1412,7 +1460,21 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     const bool fused_gm = grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
     const bool grad_cleared_by_stats = grad && !two_dof && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
     // contrast statistics per reference time
+    const bool blur_var = d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
+    double k0 = 0, k1 = 0;
+    if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
     for (int k = 0; k < d->n_ref; ++k) {
+        if (blur_var) {
+            const bool clear_grad = k == 0 && grad_cleared_by_stats;
+            ProfScope prof(h, kProfStats, s);
+            for (int rep = 0; rep < h->prof_repeat; ++rep)
+                hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h)), dim3(256), 0, s, images + k * npix, Hp, Wp, (float)k0, (float)k1,
+                                   d->omit_boundary, op.nsub, h->d_stat + k * kStatStride, h->iweb[k], zero_next ? zero_next + k * npix : nullptr,
+                                   clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0);
+            CMAX_CHECK_LAUNCH();
+            h->last_iwe[k] = h->iweb[k];
+            continue;
+        }
         const float *img = nullptr;
         rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
         if (rc) return rc;
@@ -1439,13 +1501,16 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     if (!two_dof && !grad_cleared_by_stats) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
     const EvView ev = ev_view(h);
     const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : (fused_gm ? kFoldScale : kFoldNone));
-    double k0 = 0, k1 = 0;
-    if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
     for (int k = 0; k < d->n_ref; ++k) {
         const float *gsrc = h->last_iwe[k];
         if (fold == kFoldNone || fold == kFoldScale) {
             float *Gk = d->sigma > 0 ? h->Gt : h->G;
-            if (fused_gm) {
+            if (blur_var) {
+                ProfScope prof(h, kProfGimage, s);
+                for (int rep = 0; rep < h->prof_repeat; ++rep)
+                    hipLaunchKernelGGL(k_gimage_blur_adj_var, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, (float)k0,
+                                       (float)k1, h->G);
+            } else if (fused_gm) {
                 const int gm_blocks = div_up(Hp, kGmTileH) * div_up(Wp, kGmTileW);  // one 8 x 32 pixel tile per workgroup
                 const bool clear_grad = k == 0 && grad_cleared_by_stats;
                 ProfScope prof(h, kProfStats, s);
@@ -1462,7 +1527,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
                         hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
                 }
             }
-            if (d->sigma > 0)
+            if (d->sigma > 0 && !blur_var)
                 hipLaunchKernelGGL(k_blur3_adj<float>, dim3(div_up(npix, 256)), dim3(256), 0, s, Gk, Hp, Wp, (float)k0, (float)k1, h->G);
             CMAX_CHECK_LAUNCH();
             gsrc = h->G;
