@@ -670,6 +670,88 @@ k_stats_gimage_gm(const float *__restrict__ img, int H, int W, int omit, int nsu
     if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
 }
 
+// Blurred gradient-magnitude cost (the shipped YAML cost), whole image side of one reference time in ONE kernel:
+//   Ib = blur3(I)  ->  statistics sum (gx^2 + gy^2) over Omega  ->  G' = (2/n)/8 Sobel^T(gx, gy) 1_Omega  ->  G = blur3^T G'
+// (k_blur3 + k_stats_gimage_gm + k_blur3_adj = three dependent launches of ~4.5 us each on a 260 x 346 image).
+// One 8 x 32 output tile per workgroup; the stages shrink a halo of 4 -> 3 -> 2 -> 1 -> 0 in LDS.  Arithmetic
+// order as in the separate kernels.  G leaves without its chain factor (kFoldScale).
+__global__ void __launch_bounds__(256)
+k_blur_stats_gimage_gm(const float *__restrict__ img, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_slot,
+                       float *__restrict__ blurred, float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4,
+                       float *__restrict__ G) {
+    constexpr int TH = kGmTileH, TW = kGmTileW;
+    __shared__ double smem[2 * 4];
+    __shared__ float t_i[TH + 8][TW + 8 + 1];   // raw image, halo 4 (only in-image cells are read)
+    __shared__ float t_b[TH + 6][TW + 6 + 1];   // blurred image, halo 3, zero outside the image (Sobel zero padding)
+    __shared__ float t_gx[TH + 4][TW + 4 + 1];  // Sobel/8 responses, halo 2
+    __shared__ float t_gy[TH + 4][TW + 4 + 1];
+    __shared__ float t_g[TH + 2][TW + 2 + 1];   // G', halo 1, zero outside the image
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tiles_w = (W + TW - 1) / TW;
+    const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
+    const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
+    const int i0 = omit ? 1 : 0;
+    auto in_img = [&](int r, int c) { return (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W; };
+    for (int q = threadIdx.x; q < (TH + 8) * (TW + 8); q += 256) {
+        const int a = q / (TW + 8), b = q - a * (TW + 8), r = R0 - 4 + a, c = C0 - 4 + b;
+        t_i[a][b] = in_img(r, c) ? img[(int64_t)r * W + c] : 0.f;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < (TH + 6) * (TW + 6); q += 256) {
+        const int a = q / (TW + 6), b = q - a * (TW + 6), r = R0 - 3 + a, c = C0 - 3 + b;
+        float v = 0.f;
+        if (in_img(r, c)) {  // reflect-101 neighbours are at most one pixel away: inside the halo-4 tile
+            const int rm = refl101(r - 1, H) - (R0 - 4), rr = r - (R0 - 4), rp = refl101(r + 1, H) - (R0 - 4);
+            const int cm = refl101(c - 1, W) - (C0 - 4), cc = c - (C0 - 4), cp = refl101(c + 1, W) - (C0 - 4);
+            auto row = [&](int y) { return k1 * t_i[y][cm] + k0 * t_i[y][cc] + k1 * t_i[y][cp]; };
+            v = k1 * row(rm) + k0 * row(rr) + k1 * row(rp);
+        }
+        t_b[a][b] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < (TH + 4) * (TW + 4); q += 256) {
+        const int a = q / (TW + 4), b = q - a * (TW + 4);  // response at (R0 - 2 + a, C0 - 2 + b): t_b window rows a..a+2, cols b..b+2
+        t_gx[a][b] = ((t_b[a + 2][b] + 2.f * t_b[a + 2][b + 1] + t_b[a + 2][b + 2]) - (t_b[a][b] + 2.f * t_b[a][b + 1] + t_b[a][b + 2])) * 0.125f;
+        t_gy[a][b] = ((t_b[a][b + 2] + 2.f * t_b[a + 1][b + 2] + t_b[a + 2][b + 2]) - (t_b[a][b] + 2.f * t_b[a + 1][b] + t_b[a + 2][b])) * 0.125f;
+    }
+    __syncthreads();
+    const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0);
+    for (int q = threadIdx.x; q < (TH + 2) * (TW + 2); q += 256) {
+        const int a = q / (TW + 2), b = q - a * (TW + 2), r = R0 - 1 + a, c = C0 - 1 + b;
+        float sum = 0.f;
+        if (in_img(r, c)) {
+#pragma unroll
+            for (int da = -1; da <= 1; ++da)
+#pragma unroll
+                for (int db = -1; db <= 1; ++db) {
+                    const int qi = r - da, qj = c - db;  // output pixel of the Sobel that reads (r, c) with tap (da, db)
+                    if (qi < i0 || qi >= H - i0 || qj < i0 || qj >= W - i0) continue;
+                    const float sx = (float)da * (db == 0 ? 2.f : 1.f), sy = (float)db * (da == 0 ? 2.f : 1.f);
+                    sum += t_gx[a + 1 - da][b + 1 - db] * sx + t_gy[a + 1 - da][b + 1 - db] * sy;  // (qi, qj) in halo-2 coordinates
+                }
+        }
+        t_g[a][b] = gscale * sum;
+    }
+    __syncthreads();
+    const int la = threadIdx.x / TW, lb = threadIdx.x - la * TW;
+    const int i = R0 + la, j = C0 + lb;
+    double v[2] = {0.0, 0.0};
+    if (i < H && j < W) {
+        const int64_t p = (int64_t)i * W + j;
+        blurred[p] = t_b[la + 3][lb + 3];
+        G[p] = blur_adj_1d<float>(i, H, k0, k1, [&](int r) {
+            return blur_adj_1d<float>(j, W, k0, k1, [&](int c) { return t_g[r - (R0 - 1)][c - (C0 - 1)]; });
+        });
+        if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) {
+            const float gx = t_gx[la + 2][lb + 2], gy = t_gy[la + 2][lb + 2];
+            v[0] = (double)(gx * gx + gy * gy);
+        }
+        if (zero_img) zero_img[p] = 0.f;
+    }
+    block_sum<2>(v, smem);
+    if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
+}
+
 __global__ void k_finalize(ObjParams op, const double *__restrict__ stat, double *__restrict__ result) {
     if (threadIdx.x == 0 && blockIdx.x == 0) write_result(op, stat, result);
 }
@@ -1475,6 +1557,10 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             h->last_iwe[k] = h->iweb[k];
             continue;
         }
+        if (fused_gm && d->sigma > 0) {  // k_blur_stats_gimage_gm in the backward loop blurs, too
+            h->last_iwe[k] = h->iweb[k];
+            continue;
+        }
         const float *img = nullptr;
         rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
         if (rc) return rc;
@@ -1514,10 +1600,17 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
                 const int gm_blocks = div_up(Hp, kGmTileH) * div_up(Wp, kGmTileW);  // one 8 x 32 pixel tile per workgroup
                 const bool clear_grad = k == 0 && grad_cleared_by_stats;
                 ProfScope prof(h, kProfStats, s);
-                for (int rep = 0; rep < h->prof_repeat; ++rep)
-                    hipLaunchKernelGGL(k_stats_gimage_gm, dim3(gm_blocks), dim3(256), 0, s, h->last_iwe[k], Hp, Wp, d->omit_boundary, op.nsub,
-                                       h->d_stat + k * kStatStride, zero_next ? zero_next + k * npix : nullptr,
-                                       clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0, Gk);
+                for (int rep = 0; rep < h->prof_repeat; ++rep) {
+                    if (d->sigma > 0)  // raw votes -> blurred image, statistics and the finished G (blur transpose included)
+                        hipLaunchKernelGGL(k_blur_stats_gimage_gm, dim3(gm_blocks), dim3(256), 0, s, images + k * npix, Hp, Wp, (float)k0, (float)k1,
+                                           d->omit_boundary, op.nsub, h->d_stat + k * kStatStride, h->iweb[k],
+                                           zero_next ? zero_next + k * npix : nullptr, clear_grad ? (float4 *)grad : nullptr,
+                                           clear_grad ? gcount / 4 : (int64_t)0, h->G);
+                    else
+                        hipLaunchKernelGGL(k_stats_gimage_gm, dim3(gm_blocks), dim3(256), 0, s, h->last_iwe[k], Hp, Wp, d->omit_boundary, op.nsub,
+                                           h->d_stat + k * kStatStride, zero_next ? zero_next + k * npix : nullptr,
+                                           clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0, Gk);
+                }
             } else {
                 ProfScope prof(h, kProfGimage, s);
                 for (int rep = 0; rep < h->prof_repeat; ++rep) {
@@ -1527,7 +1620,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
                         hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
                 }
             }
-            if (d->sigma > 0 && !blur_var)
+            if (d->sigma > 0 && !blur_var && !fused_gm)
                 hipLaunchKernelGGL(k_blur3_adj<float>, dim3(div_up(npix, 256)), dim3(256), 0, s, Gk, Hp, Wp, (float)k0, (float)k1, h->G);
             CMAX_CHECK_LAUNCH();
             gsrc = h->G;
