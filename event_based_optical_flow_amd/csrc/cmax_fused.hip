@@ -64,6 +64,25 @@ struct WarpParams {
     const float *motion;       // theta[2] | flow[2,H,W] | voxel[T,2,H,W]
 };
 
+// One launch of an event kernel covers every reference time of the objective (blockIdx.y): a multi-focal cost
+// warps the same events to 3 reference times, and on the solver's small batches three dependent launches per
+// kernel class were three times the launch latency.
+struct RefArgs {
+    float d[4];       // reference time as a fraction of the batch period
+    float *img[4];    // K1: vote image to fill; K3: image to gather from (dL/dIWE or the IWE itself)
+    double *stat[4];  // K1: statistics accumulators to reset (or null)
+    float *zero[4];   // K3, deferred statistics: vote image of the NEXT evaluation to clear (or null)
+    int k0;           // index of the first reference time of this launch (statistics slot, partial-sum offset)
+};
+
+// the image-space kernels of an evaluation cover all reference times in one launch as well (blockIdx.y)
+struct ImgArgs {
+    const float *in[4];  // raw votes or blurred image, per reference time
+    float *blurred[4];   // blurred image to write (kernels that blur)
+    float *zero[4];      // vote image of the next evaluation to clear (or null)
+    float *G[4];         // dL/dIWE to write
+};
+
 }  // namespace cmax
 
 struct cmax_handle_s {
@@ -588,10 +607,15 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
 //   k_blur_stats_var      Ib = blur3(I) (written: K3 / cmax_copy_iwe read it), sum Ib, sum Ib^2 over Omega, zeroing
 //   k_gimage_blur_adj_var G = blur3^T [ c (Ib - mu) 1_Omega ]  with c, mu from the finished statistics
 __global__ void __launch_bounds__(256)
-k_blur_stats_var(const float *__restrict__ img, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_slot,
-                 float *__restrict__ blurred, float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4) {
+k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
+                 float4 *__restrict__ zero_extra, int64_t n_extra4) {
     __shared__ double smem[2 * 4];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *__restrict__ img = ia.in[blockIdx.y];
+    float *__restrict__ blurred = ia.blurred[blockIdx.y];
+    float *__restrict__ zero_img = ia.zero[blockIdx.y];
+    double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
+    if (blockIdx.y == 0)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     double v[2] = {0.0, 0.0};
@@ -617,12 +641,17 @@ k_blur_stats_var(const float *__restrict__ img, int H, int W, float k0, float k1
 
 constexpr int kGmTileH = 8, kGmTileW = 32;  // pixels per workgroup of k_stats_gimage_gm (256 threads, one pixel each)
 __global__ void __launch_bounds__(256)
-k_stats_gimage_gm(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot,
-                  float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4, float *__restrict__ G) {
+k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restrict__ stat_base, float4 *__restrict__ zero_extra,
+                  int64_t n_extra4) {
     __shared__ double smem[2 * 4];
     __shared__ float tile[kGmTileH + 4][kGmTileW + 4 + 1];  // image tile with a halo of 2 (zero outside the image)
+    const float *__restrict__ img = ia.in[blockIdx.y];
+    float *__restrict__ zero_img = ia.zero[blockIdx.y];
+    float *__restrict__ G = ia.G[blockIdx.y];
+    double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
     const int64_t nthreads = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += nthreads) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.y == 0)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += nthreads) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int tiles_w = (W + kGmTileW - 1) / kGmTileW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int r0 = tr * kGmTileH - 2, c0 = tc * kGmTileW - 2;
@@ -676,10 +705,15 @@ k_stats_gimage_gm(const float *__restrict__ img, int H, int W, int omit, int nsu
 // One 8 x 32 output tile per workgroup; the stages shrink a halo of 4 -> 3 -> 2 -> 1 -> 0 in LDS.  Arithmetic
 // order as in the separate kernels.  G leaves without its chain factor (kFoldScale).
 __global__ void __launch_bounds__(256)
-k_blur_stats_gimage_gm(const float *__restrict__ img, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_slot,
-                       float *__restrict__ blurred, float *__restrict__ zero_img, float4 *__restrict__ zero_extra, int64_t n_extra4,
-                       float *__restrict__ G) {
+k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
+                       float4 *__restrict__ zero_extra, int64_t n_extra4) {
     constexpr int TH = kGmTileH, TW = kGmTileW;
+    const float *__restrict__ img = ia.in[blockIdx.y];
+    float *__restrict__ blurred = ia.blurred[blockIdx.y];
+    float *__restrict__ zero_img = ia.zero[blockIdx.y];
+    float *__restrict__ G = ia.G[blockIdx.y];
+    double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
+    if (blockIdx.y > 0) n_extra4 = 0;  // the flow-gradient buffer is cleared once
     __shared__ double smem[2 * 4];
     __shared__ float t_i[TH + 8][TW + 8 + 1];   // raw image, halo 4 (only in-image cells are read)
     __shared__ float t_b[TH + 6][TW + 6 + 1];   // blurred image, halo 3, zero outside the image (Sobel zero padding)
@@ -778,8 +812,10 @@ k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__res
 }
 
 __global__ void __launch_bounds__(256)
-k_gimage_blur_adj_var(const float *__restrict__ blurred, ObjParams op, int k, const double *__restrict__ stat, float k0, float k1,
-                      float *__restrict__ G) {
+k_gimage_blur_adj_var(ImgArgs ia, ObjParams op, const double *__restrict__ stat, float k0, float k1) {
+    const int k = blockIdx.y;
+    const float *__restrict__ blurred = ia.in[k];
+    float *__restrict__ G = ia.G[k];
     const int H = op.H, W = op.W, i0 = op.omit ? 1 : 0;
     double mud = 0.0;
     const double coef = chain_coef<true>(op, stat, k, &mud);  // every wave is converged here
@@ -1000,11 +1036,11 @@ static float ref_fraction(int ref_mode, double frac) {
 static bool wide_groups(const cmax_handle_s *h) { return h->nseg > 1024; }
 
 template <int MODEL>
-static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, float *img, double *stat_zero, hipStream_t s) {
-    const int grid = 8 * ((h->nseg + 7) / 8);
+static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, hipStream_t s) {
+    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     ProfScope prof(h, kProfVote, s);
 #define CMAX_LAUNCH_VOTE(NS, FRAC) \
-    hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, stat_zero)
+    hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra)
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
         if (wide_groups(h)) {
             if (h->has_frac) CMAX_LAUNCH_VOTE(t512, true);
@@ -1018,15 +1054,15 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 }
 
 template <int MODEL>
-static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const float *img, int fold,
-                        const ObjParams &op, int k, double *gpart, float *gflow, double *result, float *zero_img, hipStream_t s) {
-    const int grid = 8 * ((h->nseg + 7) / 8);
+static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, int fold,
+                        const ObjParams &op, double *gpart, float *gflow, double *result, hipStream_t s) {
+    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     ProfScope prof(h, kProfGrad, s);
     // dense model: runs of equal source pixel are reduced serially per thread when they are long (pixel-sorted
     // handle, >= 8 events per active pixel), else with a segmented scan per slot over lanes holding consecutive events
     const bool strided = MODEL == CMAX_MODEL_DENSE && !(h->long_runs && h->n_time_bin == 0);
 #define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, STRIDED) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, STRIDED>), dim3(grid), dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, img, op, k, h->d_stat, gpart, gflow, result, zero_img)
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, STRIDED>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
     if constexpr (MODEL == CMAX_MODEL_DENSE) {                                \
         if (strided) CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, true);                \
@@ -1067,6 +1103,7 @@ static EvView ev_view(const cmax_handle_s *h) {
 }
 
 static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T, int ref_mode, double frac, int normalize) {
+    // wp.d is what the single-reference kernels (tangent / HVP) read; the batched kernels take it from RefArgs
     WarpParams wp;
     wp.H = h->H;
     wp.W = h->W;
@@ -1083,26 +1120,40 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
     return wp;
 }
 
-// raw votes of one reference time into `raw` (zeroed here)
-static int vote_image(cmax_handle_s *h, int model, const float *motion, int T, int ref_mode, double frac, int normalize,
-                      float *raw, bool already_zero, int stat_slot, hipStream_t s) {
+// raw votes of n_ref reference times (one launch) into imgs[k] (cleared here unless bit k of zero_mask says it is
+// zero already); stat_slot0 >= 0: the statistics accumulators of slots stat_slot0 + k are reset by the launch
+static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, int n_ref, const int *ref_mode, const double *ref_frac,
+                       int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
-    if (!already_zero) CMAX_CHECK_HIP(hipMemsetAsync(raw, 0, npix * sizeof(float), s));
-    double *stat_zero = stat_slot >= 0 ? h->d_stat + stat_slot * kStatStride : nullptr;
-    if (h->n == 0) {  // no K1 launch on this rank: reset the accumulators explicitly
-        if (stat_zero) CMAX_CHECK_HIP(hipMemsetAsync(stat_zero, 0, kStatStride * sizeof(double), s));
-        return 0;
+    RefArgs ra = {};
+    ra.k0 = 0;
+    for (int k = 0; k < n_ref; ++k) {
+        if (!((zero_mask >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(imgs[k], 0, npix * sizeof(float), s));
+        double *stat_zero = stat_slot0 >= 0 ? h->d_stat + (stat_slot0 + k) * kStatStride : nullptr;
+        if (h->n == 0 && stat_zero)  // no K1 launch on this rank: reset the accumulators explicitly
+            CMAX_CHECK_HIP(hipMemsetAsync(stat_zero, 0, kStatStride * sizeof(double), s));
+        ra.d[k] = ref_fraction(ref_mode[k], ref_frac[k]);
+        ra.img[k] = imgs[k];
+        ra.stat[k] = stat_zero;
     }
+    if (h->n == 0) return 0;
     const EvView ev = ev_view(h);
-    const WarpParams wp = warp_params(h, motion, T, ref_mode, frac, normalize);
+    const WarpParams wp = warp_params(h, motion, T, ref_mode[0], ref_frac[0], normalize);
     switch (model) {
-        case CMAX_MODEL_2DOF: launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, raw, stat_zero, s); break;
-        case CMAX_MODEL_DENSE: launch_vote<CMAX_MODEL_DENSE>(h, ev, wp, raw, stat_zero, s); break;
-        case CMAX_MODEL_VOXEL: launch_vote<CMAX_MODEL_VOXEL>(h, ev, wp, raw, stat_zero, s); break;
-        default: launch_vote<-1>(h, ev, wp, raw, stat_zero, s); break;
+        case CMAX_MODEL_2DOF: launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, ra, n_ref, s); break;
+        case CMAX_MODEL_DENSE: launch_vote<CMAX_MODEL_DENSE>(h, ev, wp, ra, n_ref, s); break;
+        case CMAX_MODEL_VOXEL: launch_vote<CMAX_MODEL_VOXEL>(h, ev, wp, ra, n_ref, s); break;
+        default: launch_vote<-1>(h, ev, wp, ra, n_ref, s); break;
     }
     CMAX_CHECK_LAUNCH();
     return 0;
+}
+
+// one reference time
+static int vote_image(cmax_handle_s *h, int model, const float *motion, int T, int ref_mode, double frac, int normalize,
+                      float *raw, bool already_zero, int stat_slot, hipStream_t s) {
+    float *imgs[1] = {raw};
+    return vote_images(h, model, motion, T, 1, &ref_mode, &frac, normalize, imgs, already_zero ? 1u : 0u, stat_slot, s);
 }
 
 // the image the contrast is evaluated on: `raw`, or its blurred copy in `blur` when sigma > 0
@@ -1307,7 +1358,7 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     int rc = dev_alloc(h, &h->imgs, 2 * 5 * npix);
     for (int k = 0; k < 5 && !rc; ++k) rc = dev_alloc(h, &h->iweb[k], npix);
-    if (!rc) rc = dev_alloc(h, &h->G, npix);
+    if (!rc) rc = dev_alloc(h, &h->G, 4 * npix);  // dL/dIWE of up to 4 reference times
     if (!rc) rc = dev_alloc(h, &h->Gt, npix);
     if (!rc) rc = dev_alloc(h, &h->d_tmm, 2);
     if (!rc) rc = dev_alloc(h, &h->d_stat, kStatSlots * kStatStride);
@@ -1468,9 +1519,10 @@ static bool orig_cache_hit(const cmax_handle_s *h, const cmax_objective_t *d) {
 static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
                           int *n_images_out, hipStream_t s) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
-    for (int k = 0; k < d->n_ref; ++k) {
-        int rc = vote_image(h, d->model, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t, images + k * npix,
-                            (zero_mask >> k) & 1u, k, s);
+    {
+        float *imgs[4];
+        for (int k = 0; k < d->n_ref; ++k) imgs[k] = images + k * npix;
+        int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s);
         if (rc) return rc;
     }
     int n_images = d->n_ref;
@@ -1538,104 +1590,90 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     const bool two_dof = d->model == CMAX_MODEL_2DOF;
     const bool fold_var = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
     const bool deferred = grad && two_dof && fold_var && h->n > 0 && npix <= (int64_t)h->nseg * 8192;
-    // gradient magnitude with a gradient: K2 and K2b are one kernel (statistics + G image without its chain factor)
+    // gradient magnitude with a gradient: K2 and K2b (and the blurs) are one kernel: statistics + G image without its chain factor
     const bool fused_gm = grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
-    const bool grad_cleared_by_stats = grad && !two_dof && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
-    // contrast statistics per reference time
     const bool blur_var = d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
+    const bool grad_cleared_by_stats = grad && !two_dof && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
+    float4 *clear4 = grad_cleared_by_stats ? (float4 *)grad : nullptr;
+    const int64_t nclear4 = grad_cleared_by_stats ? gcount / 4 : 0;
     double k0 = 0, k1 = 0;
     if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
+    const dim3 gm_grid(div_up(Hp, kGmTileH) * div_up(Wp, kGmTileW), d->n_ref);  // one 8 x 32 pixel tile per workgroup
+
+    // per-reference-time pointers of the image kernels (every kernel class covers all reference times in one launch)
+    ImgArgs ia = {};
     for (int k = 0; k < d->n_ref; ++k) {
-        if (blur_var) {
-            const bool clear_grad = k == 0 && grad_cleared_by_stats;
-            ProfScope prof(h, kProfStats, s);
-            for (int rep = 0; rep < h->prof_repeat; ++rep)
-                hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h)), dim3(256), 0, s, images + k * npix, Hp, Wp, (float)k0, (float)k1,
-                                   d->omit_boundary, op.nsub, h->d_stat + k * kStatStride, h->iweb[k], zero_next ? zero_next + k * npix : nullptr,
-                                   clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0);
-            CMAX_CHECK_LAUNCH();
-            h->last_iwe[k] = h->iweb[k];
-            continue;
+        ia.in[k] = images + k * npix;
+        ia.blurred[k] = h->iweb[k];
+        ia.zero[k] = zero_next ? zero_next + k * npix : nullptr;
+        ia.G[k] = h->G + k * npix;
+        h->last_iwe[k] = d->sigma > 0 ? h->iweb[k] : images + k * npix;  // the image the contrast is evaluated on
+    }
+
+    // ---- contrast statistics
+    if (blur_var) {
+        ProfScope prof(h, kProfStats, s);
+        for (int rep = 0; rep < h->prof_repeat; ++rep)
+            hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h), d->n_ref), dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary,
+                               op.nsub, h->d_stat, clear4, nclear4);
+        CMAX_CHECK_LAUNCH();
+    } else if (!(deferred || fused_gm)) {  // those get their statistics from K3 / from the fused image kernel below
+        for (int k = 0; k < d->n_ref; ++k) {
+            const float *img = nullptr;
+            rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
+            if (rc) return rc;
+            rc = launch_stats(h, d->cost, img, d->omit_boundary, k, ia.zero[k], s, k == 0 ? (float *)clear4 : nullptr, k == 0 ? 4 * nclear4 : 0);
+            if (rc) return rc;
         }
-        if (fused_gm && d->sigma > 0) {  // k_blur_stats_gimage_gm in the backward loop blurs, too
-            h->last_iwe[k] = h->iweb[k];
-            continue;
-        }
-        const float *img = nullptr;
-        rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
-        if (rc) return rc;
-        h->last_iwe[k] = img;
-        if (deferred || fused_gm) continue;  // statistics come from K3 / from k_stats_gimage_gm in the backward loop
-        // the first statistics launch also clears the flow-gradient buffer when its size and alignment allow
-        const bool clear_grad = k == 0 && grad_cleared_by_stats;
-        rc = launch_stats(h, d->cost, img, d->omit_boundary, k, zero_next ? zero_next + k * npix : nullptr, s,
-                          clear_grad ? (float *)grad : nullptr, clear_grad ? gcount : 0);
-        if (rc) return rc;
     }
     if (!grad || h->n == 0) {  // value only (or a rank without events): the loss needs its own tiny launch
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, op, h->d_stat, result);
         CMAX_CHECK_LAUNCH();
     }
     if (!grad) return 0;
-
     if (h->n == 0) {  // this rank holds no events of the batch
         CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
         return 0;
     }
-    // backward: dL/dIWE (folded into K3 for the plain variance; otherwise G image + blur transpose)
-    // and the per-event gather, accumulated over the reference times
+
+    // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
     if (!two_dof && !grad_cleared_by_stats) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
-    const EvView ev = ev_view(h);
     const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : (fused_gm ? kFoldScale : kFoldNone));
-    for (int k = 0; k < d->n_ref; ++k) {
-        const float *gsrc = h->last_iwe[k];
-        if (fold == kFoldNone || fold == kFoldScale) {
-            float *Gk = d->sigma > 0 ? h->Gt : h->G;
-            if (blur_var) {
-                ProfScope prof(h, kProfGimage, s);
-                for (int rep = 0; rep < h->prof_repeat; ++rep)
-                    hipLaunchKernelGGL(k_gimage_blur_adj_var, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, (float)k0,
-                                       (float)k1, h->G);
-            } else if (fused_gm) {
-                const int gm_blocks = div_up(Hp, kGmTileH) * div_up(Wp, kGmTileW);  // one 8 x 32 pixel tile per workgroup
-                const bool clear_grad = k == 0 && grad_cleared_by_stats;
-                ProfScope prof(h, kProfStats, s);
-                for (int rep = 0; rep < h->prof_repeat; ++rep) {
-                    if (d->sigma > 0)  // raw votes -> blurred image, statistics and the finished G (blur transpose included)
-                        hipLaunchKernelGGL(k_blur_stats_gimage_gm, dim3(gm_blocks), dim3(256), 0, s, images + k * npix, Hp, Wp, (float)k0, (float)k1,
-                                           d->omit_boundary, op.nsub, h->d_stat + k * kStatStride, h->iweb[k],
-                                           zero_next ? zero_next + k * npix : nullptr, clear_grad ? (float4 *)grad : nullptr,
-                                           clear_grad ? gcount / 4 : (int64_t)0, h->G);
-                    else
-                        hipLaunchKernelGGL(k_stats_gimage_gm, dim3(gm_blocks), dim3(256), 0, s, h->last_iwe[k], Hp, Wp, d->omit_boundary, op.nsub,
-                                           h->d_stat + k * kStatStride, zero_next ? zero_next + k * npix : nullptr,
-                                           clear_grad ? (float4 *)grad : nullptr, clear_grad ? gcount / 4 : (int64_t)0, Gk);
-                }
-            } else {
-                ProfScope prof(h, kProfGimage, s);
-                for (int rep = 0; rep < h->prof_repeat; ++rep) {
-                    if (d->cost == CMAX_COST_VARIANCE)
-                        hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
-                    else
-                        hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(div_up(npix, 256)), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, Gk);
-                }
-            }
-            if (d->sigma > 0 && !blur_var && !fused_gm)
-                hipLaunchKernelGGL(k_blur3_adj<float>, dim3(div_up(npix, 256)), dim3(256), 0, s, Gk, Hp, Wp, (float)k0, (float)k1, h->G);
-            CMAX_CHECK_LAUNCH();
-            gsrc = h->G;
-        }
-        const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t);
-        double *gpart = h->d_gpart + (int64_t)k * h->nseg * (deferred ? 6 : 2);
-        double *res = k == d->n_ref - 1 && !deferred ? result : nullptr;  // the last K3 launch also writes the loss
-        float *zero_img = deferred && zero_next ? zero_next + k * npix : nullptr;
-        switch (d->model) {
-            case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, gsrc, fold, op, k, gpart, nullptr, res, zero_img, s); break;
-            case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, nullptr, s); break;
-            default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, gsrc, fold, op, k, nullptr, (float *)grad, res, nullptr, s); break;
+    if (blur_var) {
+        ImgArgs ib = ia;
+        for (int k = 0; k < d->n_ref; ++k) ib.in[k] = h->iweb[k];
+        ProfScope prof(h, kProfGimage, s);
+        for (int rep = 0; rep < h->prof_repeat; ++rep)
+            hipLaunchKernelGGL(k_gimage_blur_adj_var, dim3(div_up(npix, 256), d->n_ref), dim3(256), 0, s, ib, op, h->d_stat, (float)k0, (float)k1);
+        CMAX_CHECK_LAUNCH();
+    } else if (fused_gm) {
+        ProfScope prof(h, kProfStats, s);
+        for (int rep = 0; rep < h->prof_repeat; ++rep) {
+            if (d->sigma > 0)  // raw votes -> blurred image, statistics and the finished G (blur transpose included)
+                hipLaunchKernelGGL(k_blur_stats_gimage_gm, gm_grid, dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary, op.nsub,
+                                   h->d_stat, clear4, nclear4);
+            else
+                hipLaunchKernelGGL(k_stats_gimage_gm, gm_grid, dim3(256), 0, s, ia, Hp, Wp, d->omit_boundary, op.nsub, h->d_stat, clear4, nclear4);
         }
         CMAX_CHECK_LAUNCH();
     }
+    // ---- per-event gather, all reference times in one launch
+    RefArgs ra = {};
+    ra.k0 = 0;
+    for (int k = 0; k < d->n_ref; ++k) {
+        ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.img[k] = (fold == kFoldNone || fold == kFoldScale) ? h->G + k * npix : const_cast<float *>(h->last_iwe[k]);
+        ra.zero[k] = deferred ? ia.zero[k] : nullptr;
+    }
+    const EvView ev = ev_view(h);
+    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
+    double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
+    switch (d->model) {
+        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, h->d_gpart, nullptr, res, s); break;
+        case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, s); break;
+        default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, s); break;
+    }
+    CMAX_CHECK_LAUNCH();
     if (deferred) {
         hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_gpart, h->nseg, result, (double *)grad);
         CMAX_CHECK_LAUNCH();
