@@ -128,8 +128,8 @@ struct cmax_handle_s {
     double orig_sigma = -1;
     int orig_cost = -1, orig_omit = -1;
     double tmin_host = 0.0, tmax_host = 0.0;  // batch extremes (copied once per batch)
-    float *hvp_img = nullptr;                 // [6, Hp, Wp] scratch of cmax_objective_hvp (allocated on first use)
-    double *d_stat_tan = nullptr;             // [kStatStride] tangent statistics
+    float *hvp_img = nullptr;                 // [6 kinds][4 reference times][Hp, Wp] scratch of cmax_objective_hvp (allocated on first use)
+    double *d_stat_tan = nullptr;             // [4][kStatStride] tangent statistics
     int64_t bytes = 0;
     uint64_t generation = 0;  // bumped by set_events / set_time_bins (device pointers and the work list change)
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
@@ -555,8 +555,11 @@ __device__ void write_result(const ObjParams &op, const double *stat, double *__
 template <int COST>
 __global__ void __launch_bounds__(256)
 k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot, float *__restrict__ zero_img,
-        float4 *__restrict__ zero_extra, int64_t n_extra4) {
+        float4 *__restrict__ zero_extra, int64_t n_extra4, int64_t bs = 0) {
     __shared__ double smem[2 * 4];
+    img += blockIdx.y * bs;  // blockIdx.y: image of a batch (element stride bs)
+    stat_slot += blockIdx.y * kStatStride;
+    if (zero_img) zero_img += blockIdx.y * bs;
     // the flow-gradient buffer K3 accumulates into is cleared here (a hipMemsetAsync node costs 4-5 us)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned npix = (unsigned)H * (unsigned)W;
@@ -794,7 +797,10 @@ __global__ void k_finalize(ObjParams op, const double *__restrict__ stat, double
 //      the plain-variance gradient is folded into K3 instead)
 template <int COST>
 __global__ void __launch_bounds__(256)
-k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__restrict__ stat, float *__restrict__ G) {
+k_gimage(const float *__restrict__ img, ObjParams op, int k, const double *__restrict__ stat, float *__restrict__ G, int64_t bs = 0) {
+    k += blockIdx.y;  // blockIdx.y: reference time of a batch (element stride bs)
+    img += blockIdx.y * bs;
+    G += blockIdx.y * bs;
     const int H = op.H, W = op.W;
     const int i0 = op.omit ? 1 : 0;
     const double npix = region_pixels(H, W, op.omit);
@@ -841,8 +847,11 @@ k_gimage_blur_adj_var(ImgArgs ia, ObjParams op, const double *__restrict__ stat,
 // The tangent is scaled to unit max-norm by the caller so the derivative votes fit fixed point.
 // =============================================================================================
 struct TanParams {
-    const float *u;  // tangent motion, same layout as the motion, scaled to |u|_inf = 1
-    float fix, inv_fix;  // fixed-point scale of the derivative votes
+    const float *u;      // tangent motion, same layout as the motion, scaled to |u|_inf = 1
+    float fix, inv_fix;  // fixed-point scale of the derivative votes (set per workgroup from the arrays below)
+    // one launch covers the reference times of the objective (blockIdx.y):
+    float d[4], fixk[4];  // reference time as a fraction of the batch period, its fixed-point scale
+    int64_t bs;           // element stride between the per-reference-time images
 };
 
 // (da, db) of cached event slot: d(x', y')/d(motion) . u
@@ -864,8 +873,12 @@ __device__ __forceinline__ void tangent_delta(const WarpParams &wp, const TanPar
 // T2a: st[0] += sum_Omega dI (variance) or sum_Omega (gx dgx + gy dgy) (grad-mag); st[1] += sum_Omega I dI
 template <int COST>
 __global__ void __launch_bounds__(256)
-k_stats_tan(const float *__restrict__ img, const float *__restrict__ dimg, int H, int W, int omit, int nsub, double *__restrict__ st) {
+k_stats_tan(const float *__restrict__ img, const float *__restrict__ dimg, int H, int W, int omit, int nsub, double *__restrict__ st,
+            int64_t bs) {
     __shared__ double smem[2 * 4];
+    img += blockIdx.y * bs;
+    dimg += blockIdx.y * bs;
+    st += blockIdx.y * kStatStride;
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     double v[2] = {0.0, 0.0};
@@ -895,7 +908,12 @@ k_stats_tan(const float *__restrict__ img, const float *__restrict__ dimg, int H
 template <int COST>
 __global__ void __launch_bounds__(256)
 k_gimage_tan(const float *__restrict__ img, const float *__restrict__ dimg, ObjParams op, int k, const double *__restrict__ stat,
-             const double *__restrict__ st, float *__restrict__ Gp) {
+             const double *__restrict__ st, float *__restrict__ Gp, int64_t bs) {
+    k += blockIdx.y;
+    img += blockIdx.y * bs;
+    dimg += blockIdx.y * bs;
+    Gp += blockIdx.y * bs;
+    st += blockIdx.y * kStatStride;
     const int H = op.H, W = op.W, i0 = op.omit ? 1 : 0;
     const double npix = region_pixels(H, W, op.omit);
     double acc[2], tacc[2] = {0.0, 0.0};
@@ -1727,20 +1745,20 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *moti
 
 namespace cmax {
 
-// tangent votes of one reference time into `draw` (zeroed here)
+// tangent votes of every reference time (blockIdx.y) into draw + k * tp.bs (zeroed by the caller)
 template <int MODEL>
-static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, float *draw, hipStream_t s) {
-    const int grid = 8 * ((h->nseg + 7) / 8);
-    if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
-    else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, float *draw, hipStream_t s) {
+    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
+    if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+    else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
 }
 
 template <int MODEL>
-static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, const float *G,
+static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, const float *G,
                             const float *Gp, double *gpart, float *hflow, hipStream_t s) {
-    const int grid = 8 * ((h->nseg + 7) / 8);
-    if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
-    else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), dim3(grid), dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
+    if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
 }
 
 }  // namespace cmax
@@ -1761,11 +1779,19 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *
     CMAX_CHECK_HIP(hipMemsetAsync(hv, 0, gbytes, s));
     if (h->n == 0) return 0;
     if (!h->hvp_img) {
-        rc = dev_alloc(h, &h->hvp_img, 6 * npix);
-        if (!rc) rc = dev_alloc(h, &h->d_stat_tan, kStatStride);
+        rc = dev_alloc(h, &h->hvp_img, 6 * 4 * npix);
+        if (!rc) rc = dev_alloc(h, &h->d_stat_tan, 4 * kStatStride);
+        if (!rc) {
+            dev_free(&h->Gt);
+            rc = dev_alloc(h, &h->Gt, 4 * npix);
+        }
         if (rc) return rc;
     }
-    float *I = h->hvp_img, *Ib = I + npix, *dI = I + 2 * npix, *dIb = I + 3 * npix, *Gp = I + 4 * npix, *Gpt = I + 5 * npix;
+    // [6 kinds][4 reference times][npix]: every kernel of the chain covers all reference times in one launch
+    // (blockIdx.y, element stride npix)
+    const int64_t bs = npix;
+    float *I = h->hvp_img, *Ib = I + 4 * npix, *dI = I + 8 * npix, *dIb = I + 12 * npix, *Gp = I + 16 * npix, *Gpt = I + 20 * npix;
+    const int nr = d->n_ref;
 
     ObjParams op;
     op.cost = d->cost;
@@ -1796,66 +1822,79 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *
         h->orig_omit = d->omit_boundary;
     }
 
-    // derivative votes are bounded by 2 |dt|_max (the tangent has unit max-norm): fixed-point scale
+    // derivative votes are bounded by 2 |dt|_max (the tangent has unit max-norm): fixed-point scale per reference time
     const double period = d->normalize_t ? 1.0 : (h->tmax_host - h->tmin_host);
     const EvView ev = ev_view(h);
     double k0 = 0, k1 = 0;
     if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
-    const int igrid = div_up(npix, 256);
-    for (int k = 0; k < d->n_ref; ++k) {
+    const dim3 igrid(div_up(npix, 256), nr), sgrid(stat_blocks(h), nr);
+    TanParams tp = {};
+    tp.u = tangent;
+    tp.bs = bs;
+    for (int k = 0; k < nr; ++k) {
         const double dref = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
         double dtmax = fabs(dref) > fabs(1.0 - dref) ? fabs(dref) : fabs(1.0 - dref);
         dtmax *= period > 0 ? period : 1.0;
         if (dtmax < 1e-30) dtmax = 1e-30;
-        TanParams tp;
-        tp.u = tangent;
-        tp.fix = (float)(1073741824.0 / ((double)kSegMax * 2.0 * dtmax));  // 2^30 / (events * max |derivative vote|)
-        tp.inv_fix = 1.f / tp.fix;
-        const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t);
-        // image, its blur and statistics (slot k)
-        rc = vote_image(h, d->model, motion, d->T, d->ref_mode[k], d->ref_frac[k], d->normalize_t, I, false, k, s);
-        if (rc) return rc;
-        const float *img = nullptr;
-        rc = blur_image(h, d->sigma, I, Ib, &img, s);
-        if (rc) return rc;
-        rc = launch_stats(h, d->cost, img, d->omit_boundary, k, nullptr, s);
-        if (rc) return rc;
-        // T1: tangent image and its blur
-        CMAX_CHECK_HIP(hipMemsetAsync(dI, 0, npix * sizeof(float), s));
-        switch (d->model) {
-            case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, dI, s); break;
-            case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, dI, s); break;
-            default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, dI, s); break;
-        }
-        CMAX_CHECK_LAUNCH();
-        const float *dimg = nullptr;
-        rc = blur_image(h, d->sigma, dI, dIb, &dimg, s);
-        if (rc) return rc;
-        // T2: tangent statistics, G (current) and G' (tangent), blur transposes
-        const int sgrid = stat_blocks(h);
-        if (d->cost == CMAX_COST_VARIANCE) {
-            hipLaunchKernelGGL(k_stats_tan<CMAX_COST_VARIANCE>, dim3(sgrid), dim3(256), 0, s, img, dimg, Hp, Wp, d->omit_boundary, nsub, h->d_stat_tan);
-            hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(igrid), dim3(256), 0, s, img, op, k, h->d_stat, d->sigma > 0 ? h->Gt : h->G);
-            hipLaunchKernelGGL(k_gimage_tan<CMAX_COST_VARIANCE>, dim3(igrid), dim3(256), 0, s, img, dimg, op, k, h->d_stat, h->d_stat_tan, d->sigma > 0 ? Gpt : Gp);
-        } else {
-            hipLaunchKernelGGL(k_stats_tan<CMAX_COST_GRADMAG>, dim3(sgrid), dim3(256), 0, s, img, dimg, Hp, Wp, d->omit_boundary, nsub, h->d_stat_tan);
-            hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(igrid), dim3(256), 0, s, img, op, k, h->d_stat, d->sigma > 0 ? h->Gt : h->G);
-            hipLaunchKernelGGL(k_gimage_tan<CMAX_COST_GRADMAG>, dim3(igrid), dim3(256), 0, s, img, dimg, op, k, h->d_stat, h->d_stat_tan, d->sigma > 0 ? Gpt : Gp);
-        }
-        if (d->sigma > 0) {
-            hipLaunchKernelGGL(k_blur3_adj<float>, dim3(igrid), dim3(256), 0, s, h->Gt, Hp, Wp, (float)k0, (float)k1, h->G);
-            hipLaunchKernelGGL(k_blur3_adj<float>, dim3(igrid), dim3(256), 0, s, Gpt, Hp, Wp, (float)k0, (float)k1, Gp);
-        }
-        CMAX_CHECK_LAUNCH();
-        // T3
-        double *gpart = h->d_gpart + (int64_t)k * h->nseg * 2;
-        switch (d->model) {
-            case CMAX_MODEL_2DOF: launch_grad_hvp<CMAX_MODEL_2DOF>(h, ev, wp, tp, h->G, Gp, gpart, nullptr, s); break;
-            case CMAX_MODEL_DENSE: launch_grad_hvp<CMAX_MODEL_DENSE>(h, ev, wp, tp, h->G, Gp, nullptr, (float *)hv, s); break;
-            default: launch_grad_hvp<CMAX_MODEL_VOXEL>(h, ev, wp, tp, h->G, Gp, nullptr, (float *)hv, s); break;
-        }
-        CMAX_CHECK_LAUNCH();
+        tp.d[k] = (float)dref;
+        tp.fixk[k] = (float)(1073741824.0 / ((double)kSegMax * 2.0 * dtmax));  // 2^30 / (events * max |derivative vote|)
     }
+    tp.fix = tp.fixk[0];
+    tp.inv_fix = 1.f / tp.fix;
+    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
+    // images, their blur and statistics (slots 0 .. nr-1)
+    CMAX_CHECK_HIP(hipMemsetAsync(I, 0, (size_t)nr * npix * sizeof(float), s));
+    {
+        float *imgs[4];
+        for (int k = 0; k < nr; ++k) imgs[k] = I + k * npix;
+        rc = vote_images(h, d->model, motion, d->T, nr, d->ref_mode, d->ref_frac, d->normalize_t, imgs, 0xFu, 0, s);
+        if (rc) return rc;
+    }
+    const float *img = I, *dimg = dI;
+    if (d->sigma > 0) {
+        hipLaunchKernelGGL(k_blur3<float>, igrid, dim3(256), 0, s, I, Hp, Wp, (float)k0, (float)k1, Ib, bs);
+        img = Ib;
+    }
+    if (d->cost == CMAX_COST_VARIANCE)
+        hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, sgrid, dim3(256), 0, s, img, Hp, Wp, d->omit_boundary, nsub, h->d_stat, (float *)nullptr, (float4 *)nullptr, (int64_t)0, bs);
+    else
+        hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, sgrid, dim3(256), 0, s, img, Hp, Wp, d->omit_boundary, nsub, h->d_stat, (float *)nullptr, (float4 *)nullptr, (int64_t)0, bs);
+    CMAX_CHECK_LAUNCH();
+    // T1: tangent images and their blur
+    CMAX_CHECK_HIP(hipMemsetAsync(dI, 0, (size_t)nr * npix * sizeof(float), s));
+    switch (d->model) {
+        case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, dI, s); break;
+        case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, dI, s); break;
+        default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, dI, s); break;
+    }
+    CMAX_CHECK_LAUNCH();
+    if (d->sigma > 0) {
+        hipLaunchKernelGGL(k_blur3<float>, igrid, dim3(256), 0, s, dI, Hp, Wp, (float)k0, (float)k1, dIb, bs);
+        dimg = dIb;
+    }
+    // T2: tangent statistics, G (current) and G' (tangent), blur transposes
+    float *Gk = d->sigma > 0 ? h->Gt : h->G, *Gpk = d->sigma > 0 ? Gpt : Gp;
+    if (d->cost == CMAX_COST_VARIANCE) {
+        hipLaunchKernelGGL(k_stats_tan<CMAX_COST_VARIANCE>, sgrid, dim3(256), 0, s, img, dimg, Hp, Wp, d->omit_boundary, nsub, h->d_stat_tan, bs);
+        hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, igrid, dim3(256), 0, s, img, op, 0, h->d_stat, Gk, bs);
+        hipLaunchKernelGGL(k_gimage_tan<CMAX_COST_VARIANCE>, igrid, dim3(256), 0, s, img, dimg, op, 0, h->d_stat, h->d_stat_tan, Gpk, bs);
+    } else {
+        hipLaunchKernelGGL(k_stats_tan<CMAX_COST_GRADMAG>, sgrid, dim3(256), 0, s, img, dimg, Hp, Wp, d->omit_boundary, nsub, h->d_stat_tan, bs);
+        hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, igrid, dim3(256), 0, s, img, op, 0, h->d_stat, Gk, bs);
+        hipLaunchKernelGGL(k_gimage_tan<CMAX_COST_GRADMAG>, igrid, dim3(256), 0, s, img, dimg, op, 0, h->d_stat, h->d_stat_tan, Gpk, bs);
+    }
+    if (d->sigma > 0) {
+        hipLaunchKernelGGL(k_blur3_adj<float>, igrid, dim3(256), 0, s, h->Gt, Hp, Wp, (float)k0, (float)k1, h->G, bs);
+        hipLaunchKernelGGL(k_blur3_adj<float>, igrid, dim3(256), 0, s, Gpt, Hp, Wp, (float)k0, (float)k1, Gp, bs);
+    }
+    CMAX_CHECK_LAUNCH();
+    // T3
+    switch (d->model) {
+        case CMAX_MODEL_2DOF: launch_grad_hvp<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, h->G, Gp, h->d_gpart, nullptr, s); break;
+        case CMAX_MODEL_DENSE: launch_grad_hvp<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, h->G, Gp, nullptr, (float *)hv, s); break;
+        default: launch_grad_hvp<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, h->G, Gp, nullptr, (float *)hv, s); break;
+    }
+    CMAX_CHECK_LAUNCH();
     if (two_dof) {
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)hv);
         CMAX_CHECK_LAUNCH();

@@ -21,8 +21,11 @@ static inline void blur_taps(double sigma, double &k0, double &k1) {
 }
 
 // forward: out[i,j] = sum_{a,b} k[a] k[b] in[refl(i+a), refl(j+b)]
+// bs: element stride between the images of a batch (blockIdx.y), 0 for a single image
 template <typename T>
-__global__ void __launch_bounds__(256) k_blur3(const T *__restrict__ in, int H, int W, T k0, T k1, T *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_blur3(const T *__restrict__ in, int H, int W, T k0, T k1, T *__restrict__ out, int64_t bs = 0) {
+    in += blockIdx.y * bs;
+    out += blockIdx.y * bs;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)H * W) return;
     int i = (int)(p / W), j = (int)(p % W);
@@ -45,7 +48,9 @@ __device__ __forceinline__ T blur_adj_1d(int p, int n, T k0, T k1, F g) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_blur3_adj(const T *__restrict__ g, int H, int W, T k0, T k1, T *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_blur3_adj(const T *__restrict__ g, int H, int W, T k0, T k1, T *__restrict__ out, int64_t bs = 0) {
+    g += blockIdx.y * bs;
+    out += blockIdx.y * bs;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)H * W) return;
     int i = (int)(p / W), j = (int)(p % W);
