@@ -38,7 +38,8 @@ if os.path.exists(f):
                   "# native = one cmax_patch_plan_* call; autograd = the same kernels chained by torch.autograd.\n"
                   "# reference (torch-CPU fp64, BASELINE.md): 126 / 231 ms plain, 294 / 1098 ms Burgers (value+grad / hvp)\n")
         out.writelines(lines)
-short = {"k_vote": "vote", "k_stats": "stats", "k_gimage": "gimage", "k_grad": "grad", "k_finish": "finish", "k_finish_deferred": "finish"}
+short = {"k_vote": "vote", "k_stats": "stats", "k_gimage": "gimage", "k_grad": "grad", "k_finish": "finish", "k_finish_deferred": "finish",
+         "k_stats_gimage_gm": "stats", "k_blur_stats_gimage_gm": "stats", "k_blur_stats_var": "stats", "k_gimage_blur_adj_var": "gimage"}
 for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
     f = os.path.join(src, "pmc_%s.json" % wl)
     if not os.path.exists(f):
