@@ -523,6 +523,10 @@ __device__ __forceinline__ double orig_value(const ObjParams &op, const double *
 template <bool WAVE = false>
 __device__ __forceinline__ double chain_coef(const ObjParams &op, const double *stat, int k, double *mu_out) {
     const double npix = region_pixels(op.H, op.W, op.omit);
+    if (!op.normalized && op.cost != CMAX_COST_VARIANCE) {  // constant factor, no mean: the statistics are not needed
+        const double c = op.mult[k] * (op.minimize ? -1.0 : 1.0);
+        return op.negate ? -c : c;
+    }
     double acc[2];
     stat_sum<WAVE>(stat, k, op.nsub, acc);
     const double v = contrast_value(op.cost, acc, npix, mu_out);
