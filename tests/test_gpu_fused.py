@@ -319,19 +319,26 @@ def test_repeated_evaluations_are_consistent():
         assert rel_max(grad.cpu().numpy(), grad2.cpu().numpy()) <= 1e-5
 
 
-@pytest.mark.parametrize("model", ["2d-translation", "dense-flow"])
+@pytest.mark.parametrize("model", ["2d-translation", "dense-flow", "dense-flow-voxel"])
 def test_wide_workgroup_path_equals_time_sliced_sum(model):
     """Above ~2.1M events per handle the event kernels switch to 512-thread workgroups (4 events per
-    thread).  One 2.6M-event handle (wide path) must equal two 1.3M-event time slices (256-thread path)
-    combined through the phase-split API exactly like the multi-GPU run does."""
+    thread; the voxel K3 to 1024 x 2).  One 2.6M-event handle (wide path) must equal two 1.3M-event time slices
+    (256-thread path) combined through the phase-split API exactly like the multi-GPU run does."""
     size, n = (260, 346), 2_600_000
     ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=71)
-    motion = np.array([12.3, -7.7]) if model == "2d-translation" else E.utils.generate_smooth_flow(size, 15, seed=72)
-    desc = E.make_descriptor("image_variance", model, sigma=1.0)
-    whole = E.CMaxHandle(size).set_events(ev)
+    Tn = 6 if model == "dense-flow-voxel" else 0
+    if model == "2d-translation":
+        motion = np.array([12.3, -7.7])
+    elif model == "dense-flow":
+        motion = E.utils.generate_smooth_flow(size, 15, seed=72)
+    else:
+        motion = np.stack([E.utils.generate_smooth_flow(size, 15, seed=72 + b) for b in range(Tn)])
+    desc = E.make_descriptor("image_variance", model, sigma=1.0, time_bin=Tn)
+    whole = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
     res, grad = whole.evaluate(desc, motion)
     tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
-    halves = [E.CMaxHandle(size).set_events(ev[: n // 2], tmin, tmax), E.CMaxHandle(size).set_events(ev[n // 2:], tmin, tmax)]
+    halves = [E.CMaxHandle(size).set_events(ev[: n // 2], tmin, tmax, time_bin=Tn),
+              E.CMaxHandle(size).set_events(ev[n // 2:], tmin, tmax, time_bin=Tn)]
     images = sum(h.objective_vote(desc, motion) for h in halves)
     outs = [h.objective_finish(desc, motion, images) for h in halves]
     assert abs(outs[0][0][0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())
