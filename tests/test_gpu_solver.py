@@ -121,6 +121,52 @@ def test_native_plan_hvp_matches_the_autograd_path(golden):
         assert np.array_equal(w.get_hvp(x, np.zeros_like(v)), np.zeros_like(v))
 
 
+def test_native_plan_graph_replay_follows_the_handle(golden):
+    """Evaluations after the first few are replayed from captured hipGraphs.  The replay must track the handle:
+    alternating vote buffers, value-only / no-TV variants, and a new batch behind the same handle (new device
+    pointers and work list -> the graphs are dropped and re-captured)."""
+    g = golden("solver_objective")
+    k = "plain_s3"
+    size = tuple(int(v) for v in g["image_size"])
+    ev = g["events"]
+    h = E.CMaxHandle(size).set_events(ev)
+    t_scale = ev[:, 2].max() - ev[:, 2].min()
+
+    def make():
+        return PatchFlowObjective(h, t_scale, g[k + "__patch_image_size"], g[k + "__patch_size"], g[k + "__sliding_window"],
+                                  g["plain__patch_shift"], cost="hybrid", cost_with_weight=YAML_HYBRID, blur_sigma=1)
+
+    obj = make()
+    x = np.asarray(g[k + "__x"], dtype=np.float64).reshape(-1)
+    rng = np.random.default_rng(5)
+    xs = [x + rng.normal(scale=0.5, size=x.shape) for _ in range(6)]
+    w = TorchWrapper(obj, precision="float64", device="cuda")
+    w.get_input(x)
+    w.force_autograd = True
+    ref = [w.get_value_and_grad(xi) for xi in xs]  # autograd-chained path, eager launches
+    for rep in range(3):  # eager warm-up calls, then capture, then replay
+        for xi, (l_ref, g_ref) in zip(xs, ref):
+            l, gr = obj.value_and_grad_numpy(xi)
+            assert abs(l - float(l_ref)) <= 1e-6 * abs(float(l_ref))
+            assert rel_max(gr, g_ref) <= 1e-5
+            lv, _ = obj.value_and_grad_numpy(xi, want_grad=False)
+            assert abs(lv - l) <= 1e-9 * abs(l)
+    n_graphs, enabled = obj.native_plan_info()
+    assert enabled and n_graphs >= 2, (n_graphs, enabled)
+    # interleave the autograd path (it flips the handle's vote buffers behind the plan's back)
+    w.get_value_and_grad(xs[0])
+    l, gr = obj.value_and_grad_numpy(xs[1])
+    assert rel_max(gr, ref[1][1]) <= 1e-5
+    # new batch behind the same handle: half of the events
+    h.set_events(ev[: len(ev) // 2], ev[:, 2].min(), ev[:, 2].max())
+    l_half_ref, g_half_ref = w.get_value_and_grad(xs[2])
+    for _ in range(5):
+        l_half, g_half = obj.value_and_grad_numpy(xs[2])
+        assert abs(l_half - float(l_half_ref)) <= 1e-6 * abs(float(l_half_ref))
+        assert rel_max(g_half, g_half_ref) <= 1e-5
+    assert abs(l_half - float(ref[2][0])) > 1e-4 * abs(l_half)  # it really is another batch
+
+
 def test_native_plan_falls_back_for_inverse_weights(golden):
     g = golden("solver_objective")
     k = "plain_s1"
