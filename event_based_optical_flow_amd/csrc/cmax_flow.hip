@@ -20,9 +20,19 @@ template <typename T>
 __device__ __forceinline__ T dmin0(T v) { return v < (T)0 ? (T)1 : (v == (T)0 ? (T)0.5 : (T)0); }
 
 // One step.  s = sign(dt), tau = |dt|; f = s*F; out = s * f_new.   (flow_utils.py:582-639)
+// Up to 3 independent jobs per launch (blockIdx.y): the voxel is propagated from bin t0 in both time directions, and
+// the two chains advance in the same launch (a dependent launch costs ~4.5 us, a step on 2 x 260 x 346 about as much).
+// s == 0: plain copy src -> dst.
+template <typename T>
+struct StepJobs {
+    const T *src[3];
+    T *dst[3];        // forward: output; adjoint: gradient to accumulate into
+    const T *gout[3]; // adjoint only: upstream gradient
+    T s[3];
+};
+
 template <typename T, int SCHEME>
-__global__ void __launch_bounds__(256)
-k_flow_step(const T *__restrict__ F, int H, int W, T s, T tau, T *__restrict__ out) {
+__device__ __forceinline__ void flow_step_pixel(const T *__restrict__ F, int H, int W, T s, T tau, T *__restrict__ out) {
     const int64_t hw = (int64_t)H * W;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hw) return;
@@ -53,11 +63,30 @@ k_flow_step(const T *__restrict__ F, int H, int W, T s, T tau, T *__restrict__ o
     out[hw + p] = nv * s;
 }
 
+template <typename T, int SCHEME>
+__global__ void __launch_bounds__(256) k_flow_step(const T *__restrict__ F, int H, int W, T s, T tau, T *__restrict__ out) {
+    flow_step_pixel<T, SCHEME>(F, H, W, s, tau, out);
+}
+
+template <typename T, int SCHEME>
+__global__ void __launch_bounds__(256) k_flow_step_jobs(StepJobs<T> jobs, int H, int W, T tau) {
+    const int y = blockIdx.y;
+    if (jobs.s[y] == (T)0) {  // copy
+        const int64_t hw = (int64_t)H * W, p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < hw) {
+            jobs.dst[y][p] = jobs.src[y][p];
+            jobs.dst[y][hw + p] = jobs.src[y][hw + p];
+        }
+        return;
+    }
+    flow_step_pixel<T, SCHEME>(jobs.src[y], H, W, jobs.s[y], tau, jobs.dst[y]);
+}
+
 // Adjoint of one step, scatter form: the thread of output pixel (i,j) adds its contributions to
 // the gradient of every input it read.  d out / d F = d f_new / d f because s*s = 1.
 template <typename T, int SCHEME>
-__global__ void __launch_bounds__(256)
-k_flow_step_adj(const T *__restrict__ F, int H, int W, T s, T tau, const T *__restrict__ gout, T *__restrict__ gF) {
+__device__ __forceinline__ void flow_step_adj_pixel(const T *__restrict__ F, int H, int W, T s, T tau, const T *__restrict__ gout,
+                                                    T *__restrict__ gF) {
     const int64_t hw = (int64_t)H * W;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hw) return;
@@ -128,6 +157,18 @@ k_flow_step_adj(const T *__restrict__ F, int H, int W, T s, T tau, const T *__re
     }
 }
 
+template <typename T, int SCHEME>
+__global__ void __launch_bounds__(256)
+k_flow_step_adj(const T *__restrict__ F, int H, int W, T s, T tau, const T *__restrict__ gout, T *__restrict__ gF) {
+    flow_step_adj_pixel<T, SCHEME>(F, H, W, s, tau, gout, gF);
+}
+
+template <typename T, int SCHEME>
+__global__ void __launch_bounds__(256) k_flow_step_adj_jobs(StepJobs<T> jobs, int H, int W, T tau) {
+    const int y = blockIdx.y;
+    flow_step_adj_pixel<T, SCHEME>(jobs.src[y], H, W, jobs.s[y], tau, jobs.gout[y], jobs.dst[y]);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_axpy1(int64_t n, const T *__restrict__ x, T *__restrict__ y) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,39 +211,80 @@ static int flow_step_adj(const T *F, int H, int W, double dt, int scheme, const 
 }
 
 // V[t0] = F; backward steps -1/T down to 0, forward steps +1/T up to T-1 (flow_utils.py:68-79;
-// the torch loop's stray extra backward iteration, 138-139, is not reproduced).
+// the torch loop's stray extra backward iteration, 138-139, is not reproduced).  Step j of both time directions
+// (and, with j = 1, the copy of F into bin t0) share a launch.
 template <typename T>
 int voxel_construct(const T *F, int Tn, int t0, int H, int W, int scheme, T *V, hipStream_t s) {
     const int64_t sz = 2 * (int64_t)H * W;
-    const double dt = 1.0 / (double)Tn;
-    CMAX_CHECK_HIP(hipMemcpyAsync(V + (int64_t)t0 * sz, F, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
-    for (int i = t0; i > 0; --i) {
-        int rc = flow_step<T>(V + (int64_t)i * sz, H, W, -dt, scheme, V + (int64_t)(i - 1) * sz, s);
-        if (rc) return rc;
+    const T tau = (T)(1.0 / (double)Tn);
+    const int grid = div_up((int64_t)H * W, 256);
+    const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
+    if (nstep == 0) {
+        CMAX_CHECK_HIP(hipMemcpyAsync(V + (int64_t)t0 * sz, F, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+        return 0;
     }
-    for (int i = t0; i < Tn - 1; ++i) {
-        int rc = flow_step<T>(V + (int64_t)i * sz, H, W, dt, scheme, V + (int64_t)(i + 1) * sz, s);
-        if (rc) return rc;
+    for (int j = 1; j <= nstep; ++j) {
+        StepJobs<T> jobs = {};
+        int n = 0;
+        if (j <= nb) {  // bin t0-j+1 -> t0-j
+            jobs.src[n] = j == 1 ? F : V + (int64_t)(t0 - j + 1) * sz;
+            jobs.dst[n] = V + (int64_t)(t0 - j) * sz;
+            jobs.s[n++] = (T)-1;
+        }
+        if (j <= nf) {  // bin t0+j-1 -> t0+j
+            jobs.src[n] = j == 1 ? F : V + (int64_t)(t0 + j - 1) * sz;
+            jobs.dst[n] = V + (int64_t)(t0 + j) * sz;
+            jobs.s[n++] = (T)1;
+        }
+        if (j == 1) {
+            jobs.src[n] = F;
+            jobs.dst[n] = V + (int64_t)t0 * sz;
+            jobs.s[n++] = (T)0;
+        }
+        if (scheme == CMAX_SCHEME_BURGERS)
+            hipLaunchKernelGGL((k_flow_step_jobs<T, CMAX_SCHEME_BURGERS>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        else
+            hipLaunchKernelGGL((k_flow_step_jobs<T, CMAX_SCHEME_UPWIND>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        CMAX_CHECK_LAUNCH();
     }
     return 0;
 }
 
+// Adjoint sweep: the forward-time chain runs from bin T-2 down to t0, the backward-time chain from bin 1 up to t0,
+// each step adding J^T gV[neighbour] into gV[i] (atomics); step j of both chains shares a launch, the chains are
+// aligned so that they reach bin t0 in the same (last) launch.
 template <typename T>
 int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T *gV, T *gF, hipStream_t s) {
     const int64_t sz = 2 * (int64_t)H * W;
-    const double dt = 1.0 / (double)Tn;
-    for (int i = Tn - 2; i >= t0; --i) {
-        int rc = flow_step_adj<T>(V + (int64_t)i * sz, H, W, dt, scheme, gV + (int64_t)(i + 1) * sz, gV + (int64_t)i * sz, s);
-        if (rc) return rc;
-    }
-    for (int i = 1; i <= t0; ++i) {
-        int rc = flow_step_adj<T>(V + (int64_t)i * sz, H, W, -dt, scheme, gV + (int64_t)(i - 1) * sz, gV + (int64_t)i * sz, s);
-        if (rc) return rc;
+    const T tau = (T)(1.0 / (double)Tn);
+    const int grid = div_up((int64_t)H * W, 256);
+    const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
+    for (int j = nstep; j >= 1; --j) {  // j = distance of the step's INPUT bin from t0, outermost first
+        StepJobs<T> jobs = {};
+        int n = 0;
+        if (j <= nf) {  // step bin t0+j-1 -> t0+j (dt > 0): gV[t0+j-1] += J^T gV[t0+j]
+            const int i = t0 + j - 1;
+            jobs.src[n] = V + (int64_t)i * sz;
+            jobs.gout[n] = gV + (int64_t)(i + 1) * sz;
+            jobs.dst[n] = gV + (int64_t)i * sz;
+            jobs.s[n++] = (T)1;
+        }
+        if (j <= nb) {  // step bin t0-j+1 -> t0-j (dt < 0): gV[t0-j+1] += J^T gV[t0-j]
+            const int i = t0 - j + 1;
+            jobs.src[n] = V + (int64_t)i * sz;
+            jobs.gout[n] = gV + (int64_t)(i - 1) * sz;
+            jobs.dst[n] = gV + (int64_t)i * sz;
+            jobs.s[n++] = (T)-1;
+        }
+        if (scheme == CMAX_SCHEME_BURGERS)
+            hipLaunchKernelGGL((k_flow_step_adj_jobs<T, CMAX_SCHEME_BURGERS>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        else
+            hipLaunchKernelGGL((k_flow_step_adj_jobs<T, CMAX_SCHEME_UPWIND>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        CMAX_CHECK_LAUNCH();
     }
     CMAX_CHECK_HIP(hipMemcpyAsync(gF, gV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
     return 0;
 }
-
 
 template int voxel_construct<float>(const float *, int, int, int, int, int, float *, hipStream_t);
 template int voxel_construct_adj<float>(const float *, int, int, int, int, int, float *, float *, hipStream_t);
