@@ -73,6 +73,7 @@ struct RefArgs {
     double *stat[4];  // K1: statistics accumulators to reset (or null)
     float *zero[4];   // K3, deferred statistics: vote image of the NEXT evaluation to clear (or null)
     int k0;           // index of the first reference time of this launch (statistics slot, partial-sum offset)
+    int4 *win;        // [n_ref][nseg] LDS windows: written by K1, read by K3 of the same evaluation (or null)
 };
 
 // the image-space kernels of an evaluation cover all reference times in one launch as well (blockIdx.y)
@@ -109,6 +110,12 @@ struct cmax_handle_s {
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
     int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
+    int4 *d_win = nullptr;        // [4][nseg] LDS windows of the last objective vote (K1 -> K3 of the same evaluation)
+    // what those windows were computed for: K3 reuses them only for the same motion / model / reference times
+    const float *win_motion = nullptr;
+    int win_model = -2, win_nref = 0, win_T = 0, win_normalize = 0;
+    float win_d[4] = {0.f, 0.f, 0.f, 0.f};
+    uint64_t win_generation = ~(uint64_t)0;
     int nseg = 0, seg_cap = 0;
     // images
     float *imgs = nullptr;                                  // [2 buffers][5, Hp, Wp] raw votes: one per reference time + un-warped
@@ -1155,10 +1162,20 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
 // raw votes of n_ref reference times (one launch) into imgs[k] (cleared here unless bit k of zero_mask says it is
 // zero already); stat_slot0 >= 0: the statistics accumulators of slots stat_slot0 + k are reset by the launch
 static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, int n_ref, const int *ref_mode, const double *ref_frac,
-                       int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s) {
+                       int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s, bool publish_windows = false) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     RefArgs ra = {};
     ra.k0 = 0;
+    if (publish_windows && h->n > 0) {  // K3 of the same evaluation re-uses the LDS windows (see objective_finish)
+        ra.win = h->d_win;
+        h->win_motion = motion;
+        h->win_model = model;
+        h->win_nref = n_ref;
+        h->win_T = T;
+        h->win_normalize = normalize;
+        for (int k = 0; k < n_ref; ++k) h->win_d[k] = ref_fraction(ref_mode[k], ref_frac[k]);
+        h->win_generation = h->generation;
+    }
     for (int k = 0; k < n_ref; ++k) {
         if (!((zero_mask >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(imgs[k], 0, npix * sizeof(float), s));
         double *stat_zero = stat_slot0 >= 0 ? h->d_stat + (stat_slot0 + k) * kStatStride : nullptr;
@@ -1292,7 +1309,9 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
     if (h->nseg > h->seg_cap) {
         dev_free(&h->d_segs);
         dev_free(&h->d_gpart);
+        dev_free(&h->d_win);
         int rc = dev_alloc(h, &h->d_segs, h->nseg);
+        if (!rc) rc = dev_alloc(h, &h->d_win, (int64_t)4 * h->nseg);
         if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 6);
         if (rc) return rc;
         h->seg_cap = h->nseg;
@@ -1422,6 +1441,7 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->d_flags);
     dev_free(&h->d_tile_start);
     dev_free(&h->d_segs);
+    dev_free(&h->d_win);
     dev_free(&h->evp);
     dev_free(&h->rx);
     dev_free(&h->ry);
@@ -1554,7 +1574,7 @@ static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const floa
     {
         float *imgs[4];
         for (int k = 0; k < d->n_ref; ++k) imgs[k] = images + k * npix;
-        int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s);
+        int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s, true);
         if (rc) return rc;
     }
     int n_images = d->n_ref;
@@ -1692,11 +1712,15 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // ---- per-event gather, all reference times in one launch
     RefArgs ra = {};
     ra.k0 = 0;
+    bool same_vote = h->win_generation == h->generation && h->win_motion == motion && h->win_model == d->model && h->win_nref == d->n_ref &&
+                     h->win_T == d->T && h->win_normalize == d->normalize_t;
     for (int k = 0; k < d->n_ref; ++k) {
         ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
         ra.img[k] = (fold == kFoldNone || fold == kFoldScale) ? h->G + k * npix : const_cast<float *>(h->last_iwe[k]);
         ra.zero[k] = deferred ? ia.zero[k] : nullptr;
+        same_vote = same_vote && h->win_d[k] == ra.d[k];
     }
+    ra.win = same_vote ? h->d_win : nullptr;  // the windows K1 derived for exactly this warp
     const EvView ev = ev_view(h);
     const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
     double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
