@@ -396,6 +396,13 @@ constexpr int kScratch = 200;       // scratch words behind the window; the fast
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
 static_assert(kScratch >= 64 + kWinMaxW + 2, "scratch must hold a per-lane 2x2 footprint at the widest stride");
 
+// 16 bytes of zeros, written through the L2 (sc1): see the deferred-statistics K3
+typedef float float4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_zero4_sc1(float *p) {
+    const float4_v z = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(z) : "memory");
+}
+
 // v_cvt_rpi_i32_f32: floor(x + 0.5) in one instruction (rndne + cvt are two)
 __device__ __forceinline__ int cvt_rpi(float x) {
     int r;
