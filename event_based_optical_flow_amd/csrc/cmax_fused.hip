@@ -403,6 +403,18 @@ __device__ __forceinline__ void store_zero4_sc1(float *p) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(z) : "memory");
 }
 
+// Clears n floats at `base`, the launch's threads striding over it (tid of nthreads), with write-through stores:
+// buffers that the NEXT kernels fill with device-scope atomics (vote images, the flow gradient) must not stay
+// parked in an XCD's L2.  16-byte stores when the buffer allows it.
+__device__ __forceinline__ void zero_fill_sc1(float *base, int64_t n, int64_t tid, int64_t nthreads) {
+    if (!base) return;
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0) {
+        for (int64_t q = tid; q < (n >> 2); q += nthreads) store_zero4_sc1(base + 4 * q);
+    } else {
+        for (int64_t q = tid; q < n; q += nthreads) __hip_atomic_store(&base[q], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // v_cvt_rpi_i32_f32: floor(x + 0.5) in one instruction (rndne + cvt are two)
 __device__ __forceinline__ int cvt_rpi(float x) {
     int r;
@@ -579,7 +591,9 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
     stat_slot += blockIdx.y * kStatStride;
     if (zero_img) zero_img += blockIdx.y * bs;
     // the flow-gradient buffer K3 accumulates into is cleared here (a hipMemsetAsync node costs 4-5 us)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
+    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     const unsigned stride = gridDim.x * 256u;
@@ -596,7 +610,6 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
             if (COST == CMAX_COST_VARIANCE) {
                 if (in[u]) x[u] = img[p];
             }
-            if (zero_img && p < npix) zero_img[p] = 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -635,8 +648,9 @@ k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsu
     float *__restrict__ blurred = ia.blurred[blockIdx.y];
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
-    if (blockIdx.y == 0)
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
+    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     double v[2] = {0.0, 0.0};
@@ -650,7 +664,6 @@ k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsu
             v[0] += (double)b;
             v[1] += (double)b * (double)b;
         }
-        if (zero_img) zero_img[p] = 0.f;
     }
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) {
@@ -670,9 +683,9 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     float *__restrict__ G = ia.G[blockIdx.y];
     double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
-    const int64_t nthreads = (int64_t)gridDim.x * 256;
-    if (blockIdx.y == 0)
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += nthreads) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
+    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const int tiles_w = (W + kGmTileW - 1) / kGmTileW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int r0 = tr * kGmTileH - 2, c0 = tc * kGmTileW - 2;
@@ -714,7 +727,6 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
         const int64_t p = (int64_t)i * W + j;
         G[p] = gscale * s;
         if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) v[0] = (double)(gx[1][1] * gx[1][1] + gy[1][1] * gy[1][1]);
-        if (zero_img) zero_img[p] = 0.f;
     }
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
@@ -741,7 +753,9 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
     __shared__ float t_gx[TH + 4][TW + 4 + 1];  // Sobel/8 responses, halo 2
     __shared__ float t_gy[TH + 4][TW + 4 + 1];
     __shared__ float t_g[TH + 2][TW + 2 + 1];   // G', halo 1, zero outside the image
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra4; i += (int64_t)gridDim.x * 256) zero_extra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
+    zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const int tiles_w = (W + TW - 1) / TW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
@@ -801,7 +815,6 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
             const float gx = t_gx[la + 2][lb + 2], gy = t_gy[la + 2][lb + 2];
             v[0] = (double)(gx * gx + gy * gy);
         }
-        if (zero_img) zero_img[p] = 0.f;
     }
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
