@@ -154,6 +154,29 @@ def test_dense_gradient_run_reduction_regimes(n, cost, sigma):
     assert rel_max(grads[0], ref["grad"]) <= TOL
 
 
+@pytest.mark.parametrize("model,cost,sigma", [("2d-translation", "image_variance", 0), ("2d-translation", "multi_focal_normalized_image_variance", 0),
+                                              ("dense-flow", "image_variance", 0), ("dense-flow", "gradient_magnitude", 1),
+                                              ("dense-flow", "multi_focal_normalized_gradient_magnitude", 1),
+                                              ("dense-flow", "image_variance", 1)])
+def test_odd_image_size_and_repeated_evaluations(model, cost, sigma):
+    """37 x 45 = 1665 pixels: not a multiple of 4, so the 16-byte write-through clearing of the next vote image / of the
+    flow gradient falls back to 4-byte stores and the per-reference-time images are not 16-byte aligned.  Five
+    evaluations on one handle (alternating vote buffers, cached un-warped image) must all match the oracle."""
+    size, n = (37, 45), 12_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=81)
+    h = E.CMaxHandle(size).set_events(ev)
+    obj = E.ContrastObjective(h, model, cost=cost, sigma=sigma)
+    rng = np.random.default_rng(82)
+    for it in range(5):
+        motion = rng.uniform(-8, 8, 2) if model == "2d-translation" else E.utils.generate_smooth_flow(size, 6, seed=90 + it)
+        ref = orc.objective(ev, motion, model, size, cost=cost, sigma=sigma)
+        m = T(motion).requires_grad_()
+        loss = obj(m)
+        (grad,) = torch.autograd.grad(loss, m)
+        assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"]), it
+        assert rel_max(grad.cpu().numpy(), ref["grad"]) <= 2 * TOL, it
+
+
 def test_cfg4_burgers_voxel_variance():
     size, n, Tn = (130, 173), 300_000, 10
     ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=49)
