@@ -135,7 +135,7 @@ struct cmax_patch_plan_s {
     int64_t nflow = 0;     // 2 * H * W
     int64_t nmotion = 0;   // nflow or T * nflow
     double *x64 = nullptr, *v64 = nullptr, *flow64 = nullptr, *vox64 = nullptr, *gacc64 = nullptr, *gflow64 = nullptr;
-    double *gx64 = nullptr, *gtv64 = nullptr, *tv_value = nullptr, *results = nullptr, *out64 = nullptr, *d_tvw = nullptr;
+    double *gx64 = nullptr, *results = nullptr;
     float *motion32 = nullptr, *grad32 = nullptr, *tan32 = nullptr, *gx32 = nullptr;
     double *h_out_dev = nullptr;  // device view of the pinned output: the tail kernel writes the result there
     double *h_in = nullptr, *h_out = nullptr;  // pinned staging: x | v | 2 scalars, loss | grad
@@ -417,11 +417,7 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     if (!rc) rc = plan_alloc(&p->gacc64, p->nmotion);
     if (!rc && d.time_aware) rc = plan_alloc(&p->gflow64, p->nflow);
     if (!rc) rc = plan_alloc(&p->gx64, p->nx);
-    if (!rc) rc = plan_alloc(&p->gtv64, p->nx);
-    if (!rc) rc = plan_alloc(&p->tv_value, 4);
     if (!rc) rc = plan_alloc(&p->results, 8 * 4);
-    if (!rc) rc = plan_alloc(&p->out64, 1 + p->nx);
-    if (!rc) rc = plan_alloc(&p->d_tvw, 1);
     if (!rc) rc = plan_alloc(&p->motion32, p->nmotion);
     if (!rc) rc = plan_alloc(&p->grad32, p->nmotion);
     if (!rc) rc = plan_alloc(&p->tan32, p->nmotion);
@@ -434,7 +430,6 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
         (void)hipGetLastError();
         p->h_out_dev = p->h_out;  // unified addressing: pinned host memory is addressable from the device as it is
     }
-    if (!rc && hipMemcpy(p->d_tvw, &d.tv_weight, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = CMAX_ENOMEM;
     if (rc) {
         if (rc == CMAX_ENOMEM) set_error("patch_plan_create: allocation failed");
         cmax_patch_plan_destroy(p);
@@ -456,7 +451,7 @@ int cmax_patch_plan_destroy(cmax_patch_plan_t p) {
     drop_graphs(p);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->ev_caller) (void)hipEventDestroy(p->ev_caller);
-    double *d64[] = {p->x64, p->flow64, p->vox64, p->gacc64, p->gflow64, p->gx64, p->gtv64, p->tv_value, p->results, p->out64, p->d_tvw};
+    double *d64[] = {p->x64, p->flow64, p->vox64, p->gacc64, p->gflow64, p->gx64, p->results};
     for (double *q : d64)
         if (q) (void)hipFree(q);
     float *d32[] = {p->motion32, p->grad32, p->tan32, p->gx32};
