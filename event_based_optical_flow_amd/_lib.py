@@ -96,6 +96,8 @@ SIGNATURES = {
     "cmax_flow_step_adj": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_int, c_vp, c_vp, c_vp]),
     "cmax_voxel_construct": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cmax_voxel_construct_adj": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cmax_voxel_construct_tan": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cmax_voxel_construct_adj_tan": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cmax_patch_to_dense": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cmax_create": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
     "cmax_destroy": (c_int, [c_vp]),

@@ -3,6 +3,7 @@
 // 439-493 (upwind) as one gather kernel per step: each thread owns one pixel and reads its
 // 4-neighbourhood (the reference materialises ~30 intermediate ATen tensors per step).
 #include "cmax_common.h"
+#include "cmax_flow_dual.h"
 #include "cmax_patch_kernels.h"
 
 namespace cmax {
@@ -286,6 +287,70 @@ int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T 
     return 0;
 }
 
+// Voxel and its tangent along dF in one sweep (dual numbers, cmax_flow_dual.h); same launch structure as
+// voxel_construct.
+template <typename T>
+int voxel_construct_tan(const T *F, const T *dF, int Tn, int t0, int H, int W, int scheme, T *V, T *dV, hipStream_t s) {
+    const int64_t sz = 2 * (int64_t)H * W;
+    const T tau = (T)(1.0 / (double)Tn);
+    const int grid = div_up((int64_t)H * W, 256);
+    const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
+    CMAX_CHECK_HIP(hipMemcpyAsync(V + (int64_t)t0 * sz, F, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    CMAX_CHECK_HIP(hipMemcpyAsync(dV + (int64_t)t0 * sz, dF, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    for (int j = 1; j <= nstep; ++j) {
+        DualJobs<T> jobs = {};
+        int n = 0;
+        if (j <= nb) {
+            const int64_t a = (int64_t)(t0 - j + 1) * sz, b = (int64_t)(t0 - j) * sz;
+            jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.dst[n] = V + b; jobs.ddst[n] = dV + b;
+            jobs.s[n++] = (T)-1;
+        }
+        if (j <= nf) {
+            const int64_t a = (int64_t)(t0 + j - 1) * sz, b = (int64_t)(t0 + j) * sz;
+            jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.dst[n] = V + b; jobs.ddst[n] = dV + b;
+            jobs.s[n++] = (T)1;
+        }
+        if (scheme == CMAX_SCHEME_BURGERS)
+            hipLaunchKernelGGL((k_flow_step_dual<T, CMAX_SCHEME_BURGERS>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        else
+            hipLaunchKernelGGL((k_flow_step_dual<T, CMAX_SCHEME_UPWIND>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        CMAX_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// Adjoint sweep on dual numbers: gV / dgV hold (dL/dV, its tangent) on entry and are clobbered; gF = dL/dF (the
+// first-order gradient, as voxel_construct_adj gives it) and dgF = its directional derivative along dF.
+template <typename T>
+int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int W, int scheme, T *gV, T *dgV, T *gF, T *dgF, hipStream_t s) {
+    const int64_t sz = 2 * (int64_t)H * W;
+    const T tau = (T)(1.0 / (double)Tn);
+    const int grid = div_up((int64_t)H * W, 256);
+    const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
+    for (int j = nstep; j >= 1; --j) {
+        DualJobs<T> jobs = {};
+        int n = 0;
+        if (j <= nf) {
+            const int64_t a = (int64_t)(t0 + j - 1) * sz, b = (int64_t)(t0 + j) * sz;
+            jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.gout[n] = gV + b; jobs.dgout[n] = dgV + b; jobs.dst[n] = gV + a; jobs.ddst[n] = dgV + a;
+            jobs.s[n++] = (T)1;
+        }
+        if (j <= nb) {
+            const int64_t a = (int64_t)(t0 - j + 1) * sz, b = (int64_t)(t0 - j) * sz;
+            jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.gout[n] = gV + b; jobs.dgout[n] = dgV + b; jobs.dst[n] = gV + a; jobs.ddst[n] = dgV + a;
+            jobs.s[n++] = (T)-1;
+        }
+        if (scheme == CMAX_SCHEME_BURGERS)
+            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_BURGERS>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        else
+            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_UPWIND>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
+        CMAX_CHECK_LAUNCH();
+    }
+    if (gF) CMAX_CHECK_HIP(hipMemcpyAsync(gF, gV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    CMAX_CHECK_HIP(hipMemcpyAsync(dgF, dgV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 template int voxel_construct<float>(const float *, int, int, int, int, int, float *, hipStream_t);
 template int voxel_construct_adj<float>(const float *, int, int, int, int, int, float *, float *, hipStream_t);
 
@@ -330,6 +395,28 @@ int cmax_voxel_construct_adj(const void *V, int dtype, int Tn, int t0, int H, in
     if (dtype == CMAX_F32) return voxel_construct_adj<float>((const float *)V, Tn, t0, H, W, scheme, (float *)gV, (float *)gF, (hipStream_t)stream);
     if (dtype == CMAX_F64) return voxel_construct_adj<double>((const double *)V, Tn, t0, H, W, scheme, (double *)gV, (double *)gF, (hipStream_t)stream);
     set_error("voxel_construct_adj: dtype");
+    return CMAX_EINVAL;
+}
+
+int cmax_voxel_construct_tan(const void *F, const void *dF, int dtype, int Tn, int t0, int H, int W, int scheme, void *V, void *dV,
+                             cmax_stream_t stream) {
+    CMAX_REQUIRE(F && dF && V && dV && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_tan");
+    CMAX_REQUIRE(scheme == CMAX_SCHEME_BURGERS || scheme == CMAX_SCHEME_UPWIND, "voxel_construct_tan: scheme");
+    if (dtype == CMAX_F32) return voxel_construct_tan<float>((const float *)F, (const float *)dF, Tn, t0, H, W, scheme, (float *)V, (float *)dV, (hipStream_t)stream);
+    if (dtype == CMAX_F64) return voxel_construct_tan<double>((const double *)F, (const double *)dF, Tn, t0, H, W, scheme, (double *)V, (double *)dV, (hipStream_t)stream);
+    set_error("voxel_construct_tan: dtype");
+    return CMAX_EINVAL;
+}
+
+int cmax_voxel_construct_adj_tan(const void *V, const void *dV, int dtype, int Tn, int t0, int H, int W, int scheme, void *gV, void *dgV,
+                                 void *gF, void *dgF, cmax_stream_t stream) {
+    CMAX_REQUIRE(V && dV && gV && dgV && dgF && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj_tan");
+    CMAX_REQUIRE(scheme == CMAX_SCHEME_BURGERS || scheme == CMAX_SCHEME_UPWIND, "voxel_construct_adj_tan: scheme");
+    if (dtype == CMAX_F32)
+        return voxel_construct_adj_tan<float>((const float *)V, (const float *)dV, Tn, t0, H, W, scheme, (float *)gV, (float *)dgV, (float *)gF, (float *)dgF, (hipStream_t)stream);
+    if (dtype == CMAX_F64)
+        return voxel_construct_adj_tan<double>((const double *)V, (const double *)dV, Tn, t0, H, W, scheme, (double *)gV, (double *)dgV, (double *)gF, (double *)dgF, (hipStream_t)stream);
+    set_error("voxel_construct_adj_tan: dtype");
     return CMAX_EINVAL;
 }
 

@@ -304,6 +304,36 @@ def construct_dense_flow_voxel(flow, time_bin: int, scheme: str = "upwind", t0_l
     return _VoxelFn.apply(_cuda(flow, "flow"), int(time_bin), t0, SCHEME_CODES[scheme])
 
 
+def voxel_construct_tan(flow, dflow, time_bin: int, scheme: str = "burgers", t0_location: str = "middle"):
+    """(V, dV): the voxel of `flow` and its directional derivative along `dflow` (cmax_voxel_construct_tan).
+    Not differentiable itself -- a building block of exact Hessian-vector products."""
+    _lib.require_gpu()
+    flow, dflow = _cuda(flow.detach(), "flow").contiguous(), _cuda(dflow.detach(), "dflow").to(flow.dtype).contiguous()
+    t0 = 0 if t0_location == "first" else time_bin // 2
+    _, H, W = flow.shape
+    V = torch.empty((time_bin, 2, H, W), dtype=flow.dtype, device=flow.device)
+    dV = torch.empty_like(V)
+    check(_lib.load().cmax_voxel_construct_tan(_ptr(flow), _ptr(dflow), _code(flow), time_bin, t0, H, W, SCHEME_CODES[scheme],
+                                               _ptr(V), _ptr(dV), _stream()))
+    return V, dV
+
+
+def voxel_construct_adj_tan(V, dV, gV, dgV, scheme: str = "burgers", t0_location: str = "middle"):
+    """(gF, dgF) = (J^T gV, J^T dgV + (dJ[dV])^T gV) of the voxel chain at V with tangent dV (cmax_voxel_construct_adj_tan)."""
+    _lib.require_gpu()
+    V = _cuda(V.detach(), "V").contiguous()
+    T, _, H, W = V.shape
+    dV = _cuda(dV.detach(), "dV").to(V.dtype).contiguous()
+    gV = _cuda(gV.detach(), "gV").to(V.dtype).contiguous().clone()  # clobbered
+    dgV = _cuda(dgV.detach(), "dgV").to(V.dtype).contiguous().clone()
+    t0 = 0 if t0_location == "first" else T // 2
+    gF = torch.empty((2, H, W), dtype=V.dtype, device=V.device)
+    dgF = torch.empty_like(gF)
+    check(_lib.load().cmax_voxel_construct_adj_tan(_ptr(V), _ptr(dV), _code(V), T, t0, H, W, SCHEME_CODES[scheme], _ptr(gV), _ptr(dgV),
+                                                   _ptr(gF), _ptr(dgF), _stream()))
+    return gF, dgF
+
+
 # ------------------------------------------------------------------------------------------------
 class _PatchToDenseFn(torch.autograd.Function):
     @staticmethod

@@ -152,6 +152,17 @@ int cmax_voxel_construct(const void *F, int dtype, int T, int t0, int H, int W, 
 int cmax_voxel_construct_adj(const void *V, int dtype, int T, int t0, int H, int W, int scheme,
                              void *gV, void *gF, cmax_stream_t stream);
 
+/* Second order of the same chain, for exact Hessian-vector products of time-aware objectives (what
+ * torch.autograd.functional.vhp differentiates, src/solver/scipy_autograd/torch_wrapper.py:51-73):
+ *   _tan      V[T,2,H,W] and its directional derivative dV along dF, in one sweep
+ *   _adj_tan  on entry gV = dL/dV, dgV = its tangent (both clobbered); gF[2,H,W] = dL/dF (NULL: not wanted),
+ *             dgF[2,H,W] = d/d(eps) [dL/dF](F + eps dF) = J^T dgV + (dJ[dV])^T gV
+ * sign(), the selectors of maximum / minimum and |.|' are piecewise constant (torch's convention).          */
+int cmax_voxel_construct_tan(const void *F, const void *dF, int dtype, int T, int t0, int H, int W, int scheme,
+                             void *V, void *dV, cmax_stream_t stream);
+int cmax_voxel_construct_adj_tan(const void *V, const void *dV, int dtype, int T, int t0, int H, int W, int scheme,
+                                 void *gV, void *dgV, void *gF, void *dgF, cmax_stream_t stream);
+
 /* interpolate_dense_flow_from_patch_tensor (src/solver/patch_contrast_base.py:462-506): patch motion
  * [2,ph,pw] -> dense flow [2,H,W] = centre-crop(bilinear x(sw_h,sw_w), align_corners=False, of the
  * replicate-padded NEGATED grid).  adjoint != 0: `motion` is dL/dflow [2,H,W], out = dL/dmotion

@@ -366,6 +366,44 @@ def gen_solver_objective(rng):
     save("solver_objective", **out)
 
 
+def gen_solver_hvp():
+    """vhp of the whole solver objective (Newton-CG's hessp through TorchWrapper.get_hvp, torch_wrapper.py:51-73) at
+    the inputs of solver_objective.npz, plain and Burgers -> solver_hvp.npz.  The inputs are READ from that fixture."""
+    from src import solver as ref_solver
+
+    g = np.load(os.path.join(HERE, "solver_objective.npz"))
+    H, W = (int(v) for v in g["image_size"])
+    ev = g["events"]
+    te = torch.from_numpy(ev)
+    rng = np.random.default_rng(SEED + 3)
+    out = {}
+    for tag, time_aware in (("plain", False), ("burgers", True)):
+        slv_cfg = {
+            "method": "pyramidal_patch_contrast_maximization", "time_aware": time_aware,
+            "patch": {"initialize": "random", "scale": 4, "crop_height": 64, "crop_width": 80, "filter_type": "bilinear"},
+            "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
+            "cost": "hybrid", "outer_padding": 0,
+            "cost_with_weight": {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+            "iwe": {"method": "bilinear_vote", "blur_sigma": 1},
+        }
+        if time_aware:
+            slv_cfg.update({"time_bin": 10, "flow_interpolation": "burgers", "t0_flow_location": "middle"})
+        opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
+                   "parameters": {"trans_x": {"min": -150, "max": 150}, "trans_y": {"min": -150, "max": 150}}}
+        slv = ref_solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
+        slv._device = "cpu"
+        for scale in (1, 3):
+            slv.overload_patch_configuration(scale)
+            k = f"{tag}_s{scale}"
+            x = torch.from_numpy(g[k + "__x"])
+            v = torch.from_numpy(rng.normal(size=x.shape))
+            loss, hv = torch.autograd.functional.vhp(lambda z: slv.objective_scipy(z, te, {}, suppress_log=True), x, v)
+            assert abs(loss.item() - float(g[k + "__loss"])) <= 1e-12 * abs(loss.item())
+            out[k + "__v"] = v.numpy()
+            out[k + "__vhp"] = hv.numpy()
+    save("solver_hvp", **out)
+
+
 def gen_blur_numpy():
     """numpy-branch create_iwe(sigma>0) = scipy gaussian_filter (real scipy, no shim) -> blur_numpy.npz"""
     rng = np.random.default_rng(47)
@@ -429,8 +467,8 @@ def gen_core():
 
 
 if __name__ == "__main__":
-    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases]   (no argument = everything)
-    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases"]
+    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp]   (no argument = everything)
+    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -439,3 +477,5 @@ if __name__ == "__main__":
         gen_blur_numpy()
     if "hvp_cases" in which:
         gen_hvp_cases()
+    if "solver_hvp" in which:
+        gen_solver_hvp()

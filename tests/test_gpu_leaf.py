@@ -322,3 +322,39 @@ def test_numpy_branch_blur_golden(golden, sigma):
     iwe = E.EventImageConverter(size).create_iwe(g["events"], "bilinear_vote", sigma)
     assert isinstance(iwe, np.ndarray)
     np.testing.assert_allclose(iwe, g[f"iwe_numpy_s{sigma}"], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("scheme", ["burgers", "upwind"])
+@pytest.mark.parametrize("t0", ["middle", "first"])
+def test_voxel_chain_second_order_against_difference_quotients(scheme, t0):
+    """cmax_voxel_construct_tan / _adj_tan (dual numbers) in fp64: the tangent voxel equals the central difference of
+    the voxel, and dgF equals the central difference of the first-order adjoint plus its part that is linear in dgV.
+    Smooth flows keep the difference quotients away from the kinks of max / min / sign."""
+    import event_based_optical_flow_amd.functional as F
+
+    H, W, Tn = 23, 31, 7
+    rng = np.random.default_rng(7)
+    f = torch.tensor(E.utils.generate_smooth_flow((H, W), 9.0, grid=3, seed=3), dtype=torch.float64, device="cuda") + 0.37
+    df = torch.tensor(E.utils.generate_smooth_flow((H, W), 1.0, grid=4, seed=4), dtype=torch.float64, device="cuda")
+    V, dV = F.voxel_construct_tan(f, df, Tn, scheme, t0)
+    V0 = F.construct_dense_flow_voxel(f, Tn, scheme, t0)
+    assert torch.equal(V, V0)
+    eps = 1e-6
+    Vp = F.construct_dense_flow_voxel(f + eps * df, Tn, scheme, t0)
+    Vm = F.construct_dense_flow_voxel(f - eps * df, Tn, scheme, t0)
+    fd = (Vp - Vm) / (2 * eps)
+    assert (dV - fd).abs().max().item() <= 1e-6 * fd.abs().max().item()
+    # adjoint and its tangent
+    gV = torch.tensor(rng.normal(size=(Tn, 2, H, W)), dtype=torch.float64, device="cuda")
+    dgV = torch.tensor(rng.normal(size=(Tn, 2, H, W)), dtype=torch.float64, device="cuda")
+    gF, dgF = F.voxel_construct_adj_tan(V, dV, gV, dgV, scheme, t0)
+
+    def adj(flow, seed):  # first-order adjoint through autograd of the leaf operator
+        x = flow.clone().requires_grad_()
+        (g,) = torch.autograd.grad(F.construct_dense_flow_voxel(x, Tn, scheme, t0), x, grad_outputs=seed)
+        return g
+
+    g0 = adj(f, gV)
+    assert (gF - g0).abs().max().item() <= 1e-12 * g0.abs().max().item()
+    fd2 = (adj(f + eps * df, gV) - adj(f - eps * df, gV)) / (2 * eps) + adj(f, dgV)
+    assert (dgF - fd2).abs().max().item() <= 2e-6 * fd2.abs().max().item()
