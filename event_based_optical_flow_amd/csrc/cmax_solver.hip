@@ -32,10 +32,31 @@ k_convert_scale(const TI *__restrict__ in, int64_t n, double scale, const double
     if (i < n) out[i] = (TO)((double)in[i] * sc);
 }
 
-// acc (=, +=) w * g
-__global__ void __launch_bounds__(256) k_accumulate(const float *__restrict__ g, int64_t n, double w, int first, double *__restrict__ acc) {
+// acc (=, +=) w [* *w_dev] * g
+__global__ void __launch_bounds__(256)
+k_accumulate(const float *__restrict__ g, int64_t n, double w, int first, double *__restrict__ acc, const double *__restrict__ w_dev = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w_dev) w *= w_dev[0];
     if (i < n) acc[i] = (first ? 0.0 : acc[i]) + w * (double)g[i];
+}
+
+// max |x| as the bit pattern of a non-negative double (order-preserving under unsigned compare); *bits zeroed by the caller
+__global__ void __launch_bounds__(256) k_absmax(const double *__restrict__ x, int64_t n, unsigned long long *__restrict__ bits) {
+    __shared__ unsigned long long s_m;
+    if (threadIdx.x == 0) s_m = 0ull;
+    __syncthreads();
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(x[i]));
+    atomicMax(&s_m, (unsigned long long)__double_as_longlong(m));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(bits, s_m);
+}
+
+// scal[0] = max (1 if the field is all zero), scal[1] = 1 / scal[0]
+__global__ void k_absmax_finish(const unsigned long long *__restrict__ bits, double *__restrict__ scal) {
+    const double m = __longlong_as_double((long long)bits[0]);
+    scal[0] = m > 0.0 ? m : 1.0;
+    scal[1] = 1.0 / scal[0];
 }
 
 struct FinalParams {
@@ -136,6 +157,8 @@ struct cmax_patch_plan_s {
     int64_t nmotion = 0;   // nflow or T * nflow
     double *x64 = nullptr, *v64 = nullptr, *flow64 = nullptr, *vox64 = nullptr, *gacc64 = nullptr, *gflow64 = nullptr;
     double *gx64 = nullptr, *results = nullptr;
+    // time-aware Hessian-vector product (allocated on first use): tangent flow / voxel, tangent of dL/dvoxel, scalars
+    double *dflow64 = nullptr, *dvox64 = nullptr, *dgacc64 = nullptr, *dgflow64 = nullptr, *scal = nullptr;
     float *motion32 = nullptr, *grad32 = nullptr, *tan32 = nullptr, *gx32 = nullptr;
     double *h_out_dev = nullptr;  // device view of the pinned output: the tail kernel writes the result there
     double *h_in = nullptr, *h_out = nullptr;  // pinned staging: x | v | 2 scalars, loss | grad
@@ -263,8 +286,67 @@ int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t 
 }
 
 // Hessian-vector product: h_in = x | v | 1/|v|_inf | |v|_inf
+// Time-aware objective: x -> F = t P x -> voxel V(F) -> L(V).  With g_V = dL/dV, H_VV the Hessian of the fused
+// terms (cmax_objective_hvp) and J = dV/dF:
+//   H_x v = t P^T [ J^T H_VV J (t P v) + (dJ[t P v])^T g_V ]
+// J (t P v) is the tangent voxel of the dual-number sweep; the bracket is what its adjoint sweep returns for the
+// seeds (g_V, H_VV dV).  The tangent handed to cmax_objective_hvp must have max-norm <= 1, hence the device-side
+// max |dV| (the propagation can amplify the tangent).
+int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
+    const cmax_patch_objective_t &d = p->d;
+    CMAX_CHECK_HIP(hipMemcpyAsync(p->x64, p->h_in, (2 * (size_t)p->nx + 2) * sizeof(double), hipMemcpyHostToDevice, s));
+    const double *inv_vmax = p->x64 + 2 * p->nx, *vmax = inv_vmax + 1;
+    const int fgrid = div_up(p->nflow, 256), mgrid = div_up(p->nmotion, 256);
+    // F = t P x,  dF = t P v / |v|_inf
+    int rc = cmax_patch_to_dense(p->x64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 0, p->flow64, s);
+    if (rc) return rc;
+    rc = cmax_patch_to_dense(p->v64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 0, p->dflow64, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_convert_scale<double, double>), dim3(fgrid), dim3(256), 0, s, p->flow64, p->nflow, d.t_scale, (const double *)nullptr, p->flow64);
+    hipLaunchKernelGGL((k_convert_scale<double, double>), dim3(fgrid), dim3(256), 0, s, p->dflow64, p->nflow, d.t_scale, inv_vmax, p->dflow64);
+    CMAX_CHECK_LAUNCH();
+    rc = cmax_voxel_construct_tan(p->flow64, p->dflow64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->vox64, p->dvox64, s);
+    if (rc) return rc;
+    // fp32 motion and unit-norm fp32 tangent of the fused terms
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(p->scal + 2);
+    CMAX_CHECK_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_absmax, dim3(mgrid < 512 ? mgrid : 512), dim3(256), 0, s, p->dvox64, p->nmotion, bits);
+    hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(1), 0, s, bits, p->scal);
+    hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(mgrid), dim3(256), 0, s, p->vox64, p->nmotion, 1.0, (const double *)nullptr, p->motion32);
+    hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(mgrid), dim3(256), 0, s, p->dvox64, p->nmotion, 1.0, p->scal + 1, p->tan32);
+    CMAX_CHECK_LAUNCH();
+    for (int i = 0; i < d.n_terms; ++i) {
+        rc = cmax_objective(p->handle, &d.term[i], p->motion32, p->results + 8 * i, p->grad32, s);  // g_V
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_accumulate, dim3(mgrid), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64, (const double *)nullptr);
+        CMAX_CHECK_LAUNCH();
+        rc = cmax_objective_hvp(p->handle, &d.term[i], p->motion32, p->tan32, p->grad32, s);  // H_VV dV / max|dV|
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_accumulate, dim3(mgrid), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->dgacc64, (const double *)p->scal);
+        CMAX_CHECK_LAUNCH();
+    }
+    rc = cmax_voxel_construct_adj_tan(p->vox64, p->dvox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->dgacc64, nullptr, p->dgflow64, s);
+    if (rc) return rc;
+    rc = cmax_patch_to_dense(p->dgflow64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
+    if (rc) return rc;
+    FinalParams fp;
+    fp.n_terms = 0;
+    fp.with_tv = 0;  // total_variation is piecewise linear: zero Hessian almost everywhere
+    fp.nx = p->nx;
+    fp.ph = d.ph;
+    fp.pw = d.pw;
+    fp.tv_crop = 0;
+    for (int i = 0; i < 4; ++i) fp.weight[i] = 0.0;
+    fp.tv_weight = 0.0;
+    fp.gscale = d.t_scale;  // the outer t P^T; times |v|_inf from device memory
+    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, p->gx64, (const float *)nullptr, vmax, p->h_out_dev);
+    CMAX_CHECK_LAUNCH();
+    return 0;
+}
+
 int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
     const cmax_patch_objective_t &d = p->d;
+    if (d.time_aware) return enqueue_hvp_time_aware(p, s);
     // x64 | v64 | scal64 are one allocation: a single copy brings x, v and the two scalars
     CMAX_CHECK_HIP(hipMemcpyAsync(p->x64, p->h_in, (2 * (size_t)p->nx + 2) * sizeof(double), hipMemcpyHostToDevice, s));
     const double *inv_vmax = p->x64 + 2 * p->nx, *vmax = inv_vmax + 1;
@@ -451,7 +533,7 @@ int cmax_patch_plan_destroy(cmax_patch_plan_t p) {
     drop_graphs(p);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->ev_caller) (void)hipEventDestroy(p->ev_caller);
-    double *d64[] = {p->x64, p->flow64, p->vox64, p->gacc64, p->gflow64, p->gx64, p->results};
+    double *d64[] = {p->x64, p->flow64, p->vox64, p->gacc64, p->gflow64, p->gx64, p->results, p->dflow64, p->dvox64, p->dgacc64, p->dgflow64, p->scal};
     for (double *q : d64)
         if (q) (void)hipFree(q);
     float *d32[] = {p->motion32, p->grad32, p->tan32, p->gx32};
@@ -479,7 +561,14 @@ int cmax_patch_plan_evaluate(cmax_patch_plan_t p, const double *x_host, int with
 int cmax_patch_plan_hvp(cmax_patch_plan_t p, const double *x_host, const double *v_host, double *hv_host, cmax_stream_t stream) {
     CMAX_REQUIRE(p && x_host && v_host && hv_host, "patch_plan_hvp: null pointer");
     const cmax_patch_objective_t &d = p->d;
-    CMAX_REQUIRE(!d.time_aware, "patch_plan_hvp: the Burgers voxel chain has no second-order adjoint (difference the gradient instead)");
+    if (d.time_aware && !p->dvox64) {  // second-order buffers of the voxel chain, on first use
+        int rc = plan_alloc(&p->dflow64, p->nflow);
+        if (!rc) rc = plan_alloc(&p->dvox64, p->nmotion);
+        if (!rc) rc = plan_alloc(&p->dgacc64, p->nmotion);
+        if (!rc) rc = plan_alloc(&p->dgflow64, p->nflow);
+        if (!rc) rc = plan_alloc(&p->scal, 4);
+        if (rc) return rc;
+    }
     double vmax = 0.0;
     for (int j = 0; j < p->nx; ++j) vmax = fabs(v_host[j]) > vmax ? fabs(v_host[j]) : vmax;
     if (!(vmax > 0.0)) {

@@ -110,12 +110,14 @@ class PatchFlowObjective:
                                                             grad.ctypes.data if want_grad else None, F._stream()))
         return loss.value, grad
 
-    def hvp_numpy(self, x: np.ndarray, v: np.ndarray, disp_step: float = 0.05) -> np.ndarray:
-        """Hessian-vector product on host arrays: exact (cmax_patch_plan_hvp) unless time-aware, where the analytic
-        gradient of the smooth part is differenced exactly as in `hvp`."""
+    def hvp_numpy(self, x: np.ndarray, v: np.ndarray, disp_step: float = 0.05, exact: bool = True) -> np.ndarray:
+        """Hessian-vector product on host arrays through cmax_patch_plan_hvp: exact, what the reference's
+        torch.autograd.functional.vhp returns -- for time-aware objectives including the second-order adjoint of the
+        Burgers / upwind voxel chain (cmax_voxel_construct_tan / _adj_tan).  exact=False: central difference of the
+        analytic gradient of the smooth part, as in `hvp` (kept for cross-checks)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
-        if self.time_aware:
+        if self.time_aware and not exact:
             vmax = float(np.abs(v).max())
             if vmax == 0.0:
                 return np.zeros_like(v)

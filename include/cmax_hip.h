@@ -311,8 +311,9 @@ int cmax_patch_plan_info(cmax_patch_plan_t plan, int *n_graphs, int *graph_repla
  * Blocks until the result is on the host.                                                      */
 int cmax_patch_plan_evaluate(cmax_patch_plan_t plan, const double *x_host, int with_tv, double *loss_host,
                              double *grad_host, cmax_stream_t stream);
-/* Exact Hessian-vector product w.r.t. x (t_scale^2 P^T H_flow P v, cmax_objective_hvp inside); the
- * total_variation term has zero Hessian almost everywhere.  time_aware plans: CMAX_EINVAL.      */
+/* Exact Hessian-vector product w.r.t. x: t^2 P^T H_flow P v (cmax_objective_hvp inside); time-aware plans add the
+ * voxel chain, t P^T [J^T H_VV J + (dJ[.])^T g_V] t P v (cmax_voxel_construct_tan / _adj_tan).  The
+ * total_variation term has zero Hessian almost everywhere.                                      */
 int cmax_patch_plan_hvp(cmax_patch_plan_t plan, const double *x_host, const double *v_host, double *hv_host,
                         cmax_stream_t stream);
 
