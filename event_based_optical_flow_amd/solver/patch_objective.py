@@ -142,11 +142,10 @@ class PatchFlowObjective:
 
     @property
     def has_exact_hvp(self) -> bool:
-        """TorchWrapper calls `hvp` when this is True.  Time-ignorant objectives: exact (patch -> dense is
-        linear, so H_x = t^2 P^T H_flow P).  Time-aware objectives: the Burgers voxel chain is nonlinear
-        and has no second-order adjoint yet, so `hvp` differences the analytic gradient of the SMOOTH part
-        only -- differencing the whole objective would push the kinks of the total-variation term
-        (|.| has a jump in its gradient) into the curvature and stall Newton-CG."""
+        """TorchWrapper calls `hvp_numpy` / `hvp` when this is True.  Time-ignorant objectives: patch -> dense is linear,
+        so H_x = t^2 P^T H_flow P.  Time-aware objectives add the second-order adjoint of the Burgers / upwind voxel
+        chain (cmax_voxel_construct_tan / _adj_tan).  The total-variation term is piecewise linear: zero Hessian
+        almost everywhere (a difference quotient of the whole objective would push its kinks into the curvature)."""
         return self.contrast.has_exact_hvp
 
     def _smooth_grad(self, x: torch.Tensor) -> torch.Tensor:
@@ -163,7 +162,10 @@ class PatchFlowObjective:
         return g
 
     def hvp(self, x: torch.Tensor, v: torch.Tensor, disp_step: float = 0.05) -> torch.Tensor:
-        """Hessian-vector product w.r.t. the patch motion x (exact unless time-aware, see has_exact_hvp)."""
+        """Hessian-vector product w.r.t. the patch motion x on tensors (the autograd-chained path; TorchWrapper prefers
+        `hvp_numpy`, which is exact for both kinds).  Time-ignorant: exact, composed from the autograd-wrapped stages.
+        Time-aware: a central difference of the analytic gradient of the smooth part (disp_step in pixels of
+        displacement over the batch)."""
         if not self.has_exact_hvp:
             raise NotImplementedError("no HVP for 'inv'-weighted hybrid terms")
         x = x.to(self.handle.device)

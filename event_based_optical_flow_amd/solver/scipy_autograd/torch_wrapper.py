@@ -12,8 +12,7 @@ cannot double-backward through it.  Hessian-vector products come from
     cmax_objective_hvp (tangent image / tangent gradient kernels) -- the quantity the reference obtains
     from torch.autograd.functional.vhp; else
   * a central difference of the ANALYTIC gradient, Hv ~ [g(x + h v) - g(x - h v)] / (2h),
-    h = hvp_eps * (1 + |x|_inf) / |v|_inf  (time-aware objectives: the Burgers chain has no
-    second-order adjoint yet).
+    h = hvp_eps * (1 + |x|_inf) / |v|_inf  (objectives without an exact product, e.g. 'inv' hybrid weights).
 """
 from typing import Callable, Sequence, Tuple
 
