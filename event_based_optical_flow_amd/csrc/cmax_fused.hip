@@ -1072,14 +1072,6 @@ k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *_
 // ---------------------------------------------------------------------------------------------
 // host-side orchestration
 // ---------------------------------------------------------------------------------------------
-static int event_grid(int64_t n) {
-    // >= 2 workgroups per CU on 256 CUs, at least ~512 events per workgroup
-    int64_t g = (n + 511) / 512;
-    if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
-    return (int)g;
-}
-
 static float ref_fraction(int ref_mode, double frac) {
     if (ref_mode == CMAX_REF_FIRST) return 0.f;
     if (ref_mode == CMAX_REF_LAST) return 1.f;

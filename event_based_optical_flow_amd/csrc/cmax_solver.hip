@@ -9,7 +9,8 @@
 // and back through the hand-written adjoints.  The stages are the library's own C entry points (the same
 // kernels the autograd wrappers of functional.py chain one Python call at a time); what this file adds is
 // the plan that owns the intermediate buffers and the pinned staging, so that an evaluation costs one
-// ctypes call instead of ~40 Python-level operations (measured: 0.47 ms -> see DESIGN.md).
+// ctypes call instead of ~40 Python-level operations, and replays its launch sequence from a captured hipGraph
+// (measured on the cfg1-shaped objective: 0.40 ms -> 0.09 ms per value + gradient).
 // Pre/post stages run in fp64 like the reference's solver (patch_contrast_pyramid.py:186); the event
 // path is fp32 per event with fp64 reductions as everywhere in cmax_fused.hip.
 #include <cstring>
