@@ -5,26 +5,30 @@
 // src/solver/scipy_autograd/torch_wrapper.py:30-49), without ever materialising warped events:
 //
 //   set_events (once per batch)  pack to 8 B/event (12-bit row | 12-bit col | 8-bit time bin, fp32
-//                                normalised time) and counting-sort by source-pixel tile
+//                                normalised time) and counting-sort by source-pixel tile (binned handles:
+//                                by (tile, time bin)); the host cuts the sorted stream into segments
 //   K1  k_vote      one workgroup per SEGMENT (<= 2040 consecutive sorted events = a few neighbouring
 //                   source tiles): warp, bounding box of the targets, votes accumulated in an LDS
 //                   window as 12.20 fixed point with ds_add_u32 (fp32 LDS atomics run at 1/12 of the
 //                   integer rate on gfx950, profiles/r01_microbench.txt), one coalesced global
-//                   atomicAdd per touched window pixel
-//   K2  k_stats     IWE (blurred if sigma>0) -> fp64 sums of the contrast function, added to one of
-//                   `nsub` sub-accumulators per image (same-address fp64 atomics serialise at ~12 ns);
-//                   also clears the OTHER vote buffer for the next evaluation (double buffering,
-//                   so the steady state has no memset)
-//   K2b k_gimage    only when sigma>0 or the cost is gradient-based: G = dL/dIWE (chain factor from
-//                   the device-side stats), blur transpose.  Plain variance skips it: K3 forms
-//                   G = coef * (IWE - mean) on the fly
+//                   atomicAdd per touched window pixel; publishes its windows for K3
+//   K2  image kernels: k_stats (fp64 sums of the contrast function into `nsub` sub-accumulators per
+//                   image: same-address fp64 atomics serialise at ~12 ns), or fused with what follows --
+//                   k_blur_stats_var + k_gimage_blur_adj_var (variance with blur),
+//                   k_stats_gimage_gm / k_blur_stats_gimage_gm (gradient magnitude: statistics + the
+//                   unscaled G = dL/dIWE, blurs included).  They also clear the OTHER vote buffer for
+//                   the next evaluation (double buffering: no memset in the steady state) and the
+//                   flow-gradient buffer, with write-through stores.  Plain variance needs no G image:
+//                   K3 forms G = coef * (IWE - mean) on the fly
 //   K3  k_grad      per event: re-warp, gather G at the 4 corners -> dL/d(x',y') -> motion gradient
-//                   (2-DoF: per-segment fp64 partials; dense: segmented scan + one atomic per run;
-//                   voxel: LDS accumulators per source tile)
-//   k_finish        sums the per-segment partials, writes loss + gradient, re-zeroes what K1 of the
-//                   next evaluation expects to be zero
-// The event kernels live in cmax_event_kernels.inc, compiled for 256- and 512-thread workgroups
-// (namespaces t256 / t512); the host picks 512 when there are more than 1024 segments.
+//                   (2-DoF: per-segment partials, for the plain variance together with the image
+//                   statistics so that K2 is not launched at all; dense: runs of equal source pixel
+//                   reduced in registers + one segmented scan, one atomic per run; voxel: LDS
+//                   accumulators in block-scaled fixed point)
+//   k_finish / k_finish_deferred   sum the per-segment partials (2-DoF), write loss + gradient
+// Every launch covers all reference times of the objective (blockIdx.y).  The event kernels live in
+// cmax_event_kernels.inc, compiled for 256-, 512- and 1024-thread workgroups (namespaces t256 / t512 /
+// t1024); the host picks 512 above 1024 segments (1024 for the voxel K3).
 //
 // fp32 per event with the integer source pixel split from the fp32 displacement (keeps the
 // bilinear fractions accurate to ulp(displacement) instead of ulp(coordinate)); fp64 reductions.
