@@ -154,11 +154,12 @@ def main():
     handle = E.CMaxHandle((H, W))
     sliced = TimeSlicedObjective(handle)
     ev_dev = torch.from_numpy(ev).to(dev)  # fp64 [n,4] resident in HBM before anything is timed
+    sliced.set_local_events(ev_dev, time_bin=T, device=dev)  # first call: workspace allocation, code-object load
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sliced.set_local_events(ev_dev, time_bin=T, device=dev)
     torch.cuda.synchronize()
-    prepare_ms = (time.perf_counter() - t0) * 1e3  # once per batch: pack + counting sort (not in `value`)
+    prepare_ms = (time.perf_counter() - t0) * 1e3  # once per batch: pack + counting sort + work list (not in `value`)
 
     if cfg["model"] == "dense-flow-voxel":
         f0 = torch.from_numpy(E.utils.generate_smooth_flow((H, W), 20, seed=1046)).to(dev)
