@@ -11,6 +11,7 @@ __device__ __forceinline__ unsigned hash(unsigned x) {
 // MODE 0: random f32, 1: conflict-free f32 (lane -> lane + 64*k), 2: random u32, 3: conflict-free u32,
 // 4: same-address f32 (all lanes one address), 5: random f32 but 2x2 quad per "event" (p, p+1, p+W, p+W+1)
 // 6: 4-lane duplicates (lanes 4k..4k+3 share an address)   7: plain non-atomic ds_write random (lower bound)
+// 8: random u64 (8-byte aligned)   9: u32 2x2 quads (the K1 vote pattern)   10: u64 pairs = 2x2 quad as two 8-byte adds
 template <int MODE>
 __global__ void __launch_bounds__(256) k_lds(float *out, int per_thread) {
     __shared__ float w[4096 + 128];
@@ -36,6 +37,17 @@ __global__ void __launch_bounds__(256) k_lds(float *out, int per_thread) {
         }
         if (MODE == 6) unsafeAtomicAdd(&w[hash((t >> 2) * 977u + i) & 4095u], 1.0f);
         if (MODE == 7) w[p] = (float)i;
+        if (MODE == 8) atomicAdd(reinterpret_cast<unsigned long long *>(w) + (p >> 1), 0x0000000300000005ull);
+        if (MODE == 9) {
+            atomicAdd(&wu[p], 3u);
+            atomicAdd(&wu[p + 1], 3u);
+            atomicAdd(&wu[p + 64], 3u);
+            atomicAdd(&wu[p + 65], 3u);
+        }
+        if (MODE == 10) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(w) + (p >> 1), 0x0000000300000005ull);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w) + (p >> 1) + 32, 0x0000000300000005ull);
+        }
     }
     __syncthreads();
     float s = 0;
@@ -72,5 +84,8 @@ int main() {
     run("f32 random 2x2 quads", k_lds<5>, 4);
     run("f32 4-lane duplicates", k_lds<6>, 1);
     run("plain ds_write random", k_lds<7>, 1);
+    run("u64 random", k_lds<8>, 1);
+    run("u32 random 2x2 quads (per quad)", k_lds<9>, 1);
+    run("u64 pairs = 2x2 quad (per quad)", k_lds<10>, 1);
     return 0;
 }
