@@ -229,7 +229,7 @@ k_pack_hist(const T *__restrict__ ev, int64_t n, int H, int W, int ntc, uint32_t
         if (fx >= (T)0 && fx < (T)H && fy >= (T)0 && fy < (T)W) {  // NaN fails every comparison -> dropped
             int ix = (int)fx, iy = (int)fy;
             k = (uint32_t)(((ix / kTile) * ntc + (iy / kTile)) * (kTile * kTile) + (ix % kTile) * kTile + (iy % kTile));
-            if (atomicAdd(&counts[k], 1) == 0) atomicAdd(&flags[2], 1);
+            atomicAdd(&counts[k], 1);
             if (x != fx || y != fy) flags[0] = 1;
         } else {
             atomicAdd(&flags[1], 1);
@@ -243,17 +243,31 @@ k_pack_hist(const T *__restrict__ ev, int64_t n, int H, int W, int ntc, uint32_t
 // 921k pixel keys of a 1280x720 sensor took 1.4 ms).
 constexpr int kScanChunk = 2048;  // elements per workgroup (256 threads x 8)
 
-__global__ void __launch_bounds__(256) k_scan_sums(const int *__restrict__ counts, int m, int *__restrict__ chunk_sum) {
-    __shared__ int s_w[4];
+// nonzero (optional): += number of keys with at least one event (one atomic per workgroup)
+__global__ void __launch_bounds__(256) k_scan_sums(const int *__restrict__ counts, int m, int *__restrict__ chunk_sum, int *__restrict__ nonzero) {
+    __shared__ int s_w[4], s_n[4];
     const int base = blockIdx.x * kScanChunk + threadIdx.x * 8;
-    int s = 0;
+    int s = 0, nz = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += base + u < m ? counts[base + u] : 0;
+    for (int u = 0; u < 8; ++u) {
+        const int c = base + u < m ? counts[base + u] : 0;
+        s += c;
+        nz += c != 0;
+    }
 #pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = s;
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, kWave);
+        nz += __shfl_xor(nz, o, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        s_w[threadIdx.x / kWave] = s;
+        s_n[threadIdx.x / kWave] = nz;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) {
+        chunk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (nonzero) atomicAdd(nonzero, s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+    }
 }
 
 // one workgroup: exclusive scan of the chunk sums in place (nchunk <= 1024 * per-thread loop), total -> *total_out
@@ -1123,9 +1137,9 @@ k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *_
 // host-side orchestration
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of h->counts[0..m) in place, counts[m] = total
-static void launch_scan(cmax_handle_s *h, int m, hipStream_t s) {
+static void launch_scan(cmax_handle_s *h, int m, hipStream_t s, int *nonzero = nullptr) {
     const int nchunk = div_up(m, kScanChunk);
-    hipLaunchKernelGGL(k_scan_sums, dim3(nchunk), dim3(256), 0, s, h->counts, m, h->scan_tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nchunk), dim3(256), 0, s, h->counts, m, h->scan_tmp, nonzero);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, h->scan_tmp, nchunk, h->counts + m);
     hipLaunchKernelGGL(k_scan_apply, dim3(nchunk), dim3(256), 0, s, h->counts, m, h->scan_tmp);
 }
@@ -1581,7 +1595,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     const int grid = stream_grid(n, 256);
     if (dtype == CMAX_F32) hipLaunchKernelGGL(k_pack_hist<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->H, h->W, h->ntc, h->key_tmp, h->counts, h->d_flags);
     else hipLaunchKernelGGL(k_pack_hist<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->H, h->W, h->ntc, h->key_tmp, h->counts, h->d_flags);
-    launch_scan(h, h->nkeys, s);
+    launch_scan(h, h->nkeys, s, h->d_flags + 2);  // also counts the source pixels that hold events
     if (dtype == CMAX_F32) hipLaunchKernelGGL(k_scatter<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
     else hipLaunchKernelGGL(k_scatter<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
     CMAX_CHECK_LAUNCH();
