@@ -245,7 +245,9 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *desc_host, const
  *   cmax_objective_finish  blur, contrast statistics, loss (identical on every GPU), then the
  *                          gradient contribution of THIS slice's events
  *   -- caller all-reduces (sum) grad --
- * images: fp32 [5, Hp, Wp] caller-owned.  cmax_objective == vote + finish on internal images.  */
+ * images: fp32 [5, Hp, Wp] caller-owned.  cmax_objective == vote + finish on internal images.
+ * `motion` of the finish call must be the buffer AND the values of the preceding vote call: the gather re-uses
+ * the LDS windows the vote derived for every segment.                                          */
 int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
                         float *images, int *n_images_host, cmax_stream_t stream);
 int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
