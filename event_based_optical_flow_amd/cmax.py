@@ -199,6 +199,26 @@ class CMaxHandle:
                                               grad.data_ptr() if grad is not None else None, F._stream()))
         return result, grad
 
+    # -- per-patch translation search (pyramid re-initialisation) ----------------------------------------
+    def patch_search(self, boxes, patch_image_size: Tuple[int, int], candidates, sigma: float = 1.0):
+        """Score translation candidates per patch with the reference's small-patch cost
+        (calculate_cost_for_small_patch, src/solver/patch_contrast_pyramid.py:372-414) in one launch.
+          boxes [n_patch, 4] = x_min, x_max, y_min, y_max (rows first, sensor coordinates; crop_event semantics)
+          candidates [n_patch, n_cand, 2] pixel per unit of the raw timestamps
+        -> (loss [n_patch, n_cand] = GM(un-warped) / GM(warped)  (NormalizedGradientMagnitude, "minimize"),
+            gm [n_patch, n_cand + 1] raw gradient magnitudes (last column: un-warped), count [n_patch])."""
+        b = torch.as_tensor(np.asarray(boxes), dtype=torch.int32).reshape(-1, 4).contiguous().to(self.device)
+        c = torch.as_tensor(np.asarray(candidates) if not isinstance(candidates, torch.Tensor) else candidates)
+        c = c.to(device=self.device, dtype=torch.float32).reshape(b.shape[0], -1, 2).contiguous()
+        n_patch, n_cand = int(b.shape[0]), int(c.shape[1])
+        gm = torch.empty((n_patch, n_cand + 1), dtype=torch.float32, device=self.device)
+        count = torch.empty(n_patch, dtype=torch.int32, device=self.device)
+        check(self._lib.cmax_patch_search(self._h, n_patch, b.data_ptr(), int(patch_image_size[0]), int(patch_image_size[1]),
+                                          n_cand, c.data_ptr() if n_cand else None, float(sigma), gm.data_ptr(),
+                                          count.data_ptr(), F._stream()))
+        loss = gm[:, -1:].double() / gm[:, :-1].double()
+        return loss, gm, count
+
     # -- per-kernel timing (bench.py roofline) ---------------------------------------------------------
     def set_profiling(self, enable, repeat: int = 1):
         """enable: bracket every hot launch with HIP events.  repeat > 1: issue each hot launch `repeat` times

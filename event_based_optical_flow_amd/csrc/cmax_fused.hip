@@ -37,6 +37,7 @@
 
 #include "cmax_common.h"
 #include "cmax_image_kernels.h"
+#include "cmax_search_kernels.h"
 
 namespace cmax {
 
@@ -142,6 +143,8 @@ struct cmax_handle_s {
     double tmin_host = 0.0, tmax_host = 0.0;  // batch extremes (copied once per batch)
     float *hvp_img = nullptr;                 // [6 kinds][4 reference times][Hp, Wp] scratch of cmax_objective_hvp (allocated on first use)
     double *d_stat_tan = nullptr;             // [4][kStatStride] tangent statistics
+    float2 *search_range = nullptr;           // [search_cap] (tau_min, tau_max) per patch of cmax_patch_search
+    int search_cap = 0;
     int64_t bytes = 0;
     uint64_t generation = 0;  // bumped by set_events / set_time_bins (device pointers and the work list change)
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
@@ -1520,6 +1523,7 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->d_stat);
     dev_free(&h->hvp_img);
     dev_free(&h->d_stat_tan);
+    dev_free(&h->search_range);
     dev_free(&h->d_gpart);
     dev_free(&h->counts);
     dev_free(&h->cursor);
@@ -2070,6 +2074,50 @@ int cmax_copy_iwe(cmax_handle_t h, int k, float *iwe_out, cmax_stream_t stream) 
     }
     CMAX_CHECK_HIP(hipMemcpyAsync(iwe_out, h->last_iwe[k], (size_t)h->Hp * h->Wp * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
+    return 0;
+}
+
+int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h, int img_w, int n_cand, const float *cand,
+                      double sigma, float *gm_out, int *count_out, cmax_stream_t stream) {
+    CMAX_REQUIRE(h && boxes && gm_out && count_out, "patch_search: null argument");
+    CMAX_REQUIRE(n_patch > 0 && n_cand >= 0 && (n_cand == 0 || cand), "patch_search: n_patch > 0, n_cand >= 0");
+    CMAX_REQUIRE(img_h > 0 && img_w > 0 && sigma >= 0.0, "patch_search: patch image size / sigma");
+    CMAX_REQUIRE(n_cand < 65535, "patch_search: at most 65534 candidates per patch");
+    const size_t lds = (size_t)2 * img_h * img_w * sizeof(float);
+    if (lds > 64 * 1024 - 256) {
+        set_error("patch_search: a %d x %d patch image does not fit the 64 KB workgroup LDS budget", img_h, img_w);
+        return CMAX_EINVAL;
+    }
+    if (h->n == 0) {
+        set_error("patch_search: no events set");
+        return CMAX_ESTATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (n_patch > h->search_cap) {
+        dev_free(&h->search_range);
+        h->search_cap = 0;
+        int rc = dev_alloc(h, &h->search_range, (size_t)n_patch);
+        if (rc) return rc;
+        h->search_cap = n_patch;
+    }
+    SearchArgs a;
+    a.evp = h->evp;
+    a.rx = h->rx;
+    a.ry = h->ry;
+    a.tile_start = h->d_tile_start;
+    a.groups_per_tile = h->n_time_bin > 0 ? h->n_time_bin : 1;
+    a.ntr = h->ntr;
+    a.ntc = h->ntc;
+    a.has_frac = h->has_frac ? 1 : 0;
+    a.boxes = (const int4 *)boxes;
+    a.img_h = img_h;
+    a.img_w = img_w;
+    hipLaunchKernelGGL(k_search_range, dim3(n_patch), dim3(kSearchThreads), 0, s, a, h->search_range, count_out);
+    CMAX_CHECK_LAUNCH();
+    const int radius = sigma > 0.0 ? (int)(4.0 * sigma + 0.5) : 0;  // scipy.ndimage.gaussian_filter, truncate = 4
+    hipLaunchKernelGGL(k_patch_search, dim3(n_patch, n_cand + 1), dim3(kSearchThreads), lds, s, a, h->search_range, n_cand,
+                       (const float2 *)cand, (float)(h->tmax_host - h->tmin_host), (float)sigma, radius, gm_out);
+    CMAX_CHECK_LAUNCH();
     return 0;
 }
 

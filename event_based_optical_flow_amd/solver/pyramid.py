@@ -8,10 +8,13 @@ optimizer_cfg, output_cfg, None).optimize(events)` works as in `main.py:141-179`
 What is the same: the patch grids per scale (prepare_patch / prepare_pyramidal_patch, lines 69-100),
 the objective per scale (`PatchFlowObjective` == `objective_scipy`, pinned by golden fixtures), the
 SciPy method and options, warm start from the previous frame, fine-to-coarse feedback.
+The per-patch re-initialisation at finer scales (initialize_guess_from_optuna_sampling, lines 320-353) uses the
+reference's small-patch cost (calculate_cost_for_small_patch, 372-414: pinned by tests/golden/patch_search.npz) and
+the reference's search box (sampling_initial, 417-428) -- but the trial points come from a regular grid scored in
+one GPU launch (CMaxHandle.patch_search / cmax_patch_search) instead of Optuna's sequential TPE sampler.
 What differs, and is NOT pinned against the reference (its dependencies are absent from this image and
 its trajectories depend on Optuna's TPE sampler):
-  * per-patch Optuna re-initialisation at finer scales (lines 320-428) is not reproduced -- finer
-    scales start from the expanded coarser solution;
+  * WHICH points of the search box are tried (grid vs. TPE), hence the starting point of the finer scales;
   * skimage.transform.pyramid_expand / pyramid_reduce (lines 220-222, 265-267) are restated with
     scipy.ndimage (order-1 zoom + Gaussian sigma = 2*2/6, 'reflect') on the tiny [2,ph,pw] arrays.
 These are host-side operations on a few hundred numbers between scales, not part of the hot path.
@@ -34,6 +37,13 @@ SCIPY_OPTIMIZERS = ["Nelder-Mead", "Powell", "CG", "BFGS", "Newton-CG", "L-BFGS-
 
 def _check_key_and_bool(config: dict, key: str) -> bool:
     return key in config.keys() and bool(config[key])
+
+
+def search_box(m0: np.ndarray, abs_range: float = 10.0):
+    """sampling_initial (patch_contrast_pyramid.py:417-428): per component the interval spanned by
+    {0.8 m, m - 10, 1.2 m, m + 10}.  m0 [...]: -> (lo, hi) of the same shape."""
+    c = np.stack([0.8 * m0, m0 - abs_range, 1.2 * m0, m0 + abs_range])
+    return c.min(axis=0), c.max(axis=0)
 
 
 def pyramid_expand(motion: np.ndarray) -> np.ndarray:
@@ -100,6 +110,7 @@ class PyramidalPatchContrastMaximization:
         self.total_n_patch = sum(self.scaled_n_patch.values())
         self.previous_frame_best_estimation: Optional[Dict[int, np.ndarray]] = None
         self.history = []  # (scale, OptimizeResult)
+        self.search_history = []  # (scale, candidates, loss, picked index) of the per-patch re-initialisation
 
     # -- reference API ---------------------------------------------------------------------------
     def set_previous_frame_best_estimation(self, previous_best):
@@ -120,6 +131,7 @@ class PyramidalPatchContrastMaximization:
         t_scale = float(t.max() - t.min()) if self.normalize_t_in_batch else 1.0
         best: Dict[int, np.ndarray] = {}
         self.history = []
+        self.search_history = []
         for s in range(self.coarest_scale, self.patch_scales):
             pis = self.scaled_patch_image_size[s]
             objective = PatchFlowObjective(
@@ -133,6 +145,7 @@ class PyramidalPatchContrastMaximization:
                 x0 = pyramid_expand(best[s - 1])[:, : pis[0], : pis[1]].reshape(-1)
                 if self.previous_frame_best_estimation is not None:
                     x0 = (x0 + self.previous_frame_best_estimation[s].reshape(-1)) / 2
+                x0 = self.initialize_guess_from_patch_search(handle, s, x0)
             elif self.slv_config["patch"]["initialize"] == "zero":
                 x0 = np.zeros(2 * self.scaled_n_patch[s])
             else:
@@ -147,6 +160,48 @@ class PyramidalPatchContrastMaximization:
             best[s] = np.asarray(res.x).reshape((2,) + pis)
         self._last_handle, self._last_t_scale = handle, t_scale
         return self.update_coarse_from_fine(best)
+
+    def patch_boxes(self, s: int) -> np.ndarray:
+        """[n_patch, 4] = x_min, x_max, y_min, y_max of scale s: FlowPatch bounds (src/types/flow_patch.py:29-42) of the
+        centres prepare_patch lays out (patch_contrast_base.py:86-105).  As in the reference, these boxes live on the
+        CROPPED grid without the (image - crop) / 2 shift the dense interpolation applies (patch_contrast_pyramid.py:
+        325-335 crops the raw events with them)."""
+        h, w = self.scaled_patch_size[s]
+        cx = np.arange(0, self.cropped_image_shape[0], h) + h / 2
+        cy = np.arange(0, self.cropped_image_shape[1], w) + w / 2
+        xx, yy = np.meshgrid(cx, cy, indexing="ij")
+        xx, yy = xx.reshape(-1), yy.reshape(-1)
+        return np.stack([(xx - np.ceil(h / 2)).astype(int), (xx + np.floor(h / 2)).astype(int),
+                         (yy - np.ceil(w / 2)).astype(int), (yy + np.floor(w / 2)).astype(int)], axis=1)
+
+    def initialize_guess_from_patch_search(self, handle: CMaxHandle, s: int, motion0: np.ndarray) -> np.ndarray:
+        """Role of initialize_guess_from_optuna_sampling (patch_contrast_pyramid.py:320-353): per patch, the best
+        translation inside sampling_initial's box around motion0 under the small-patch cost; patches with <= 10 events
+        keep motion0.  n_iter / (s - coarsest) trials per patch like the reference, placed on a g x g grid
+        (g = ceil(sqrt(trials)), or patch["search_grid"]) plus motion0 itself; all patches and trials in one launch."""
+        m0 = np.asarray(motion0, dtype=np.float64).reshape(2, -1)  # [2, n_patch]
+        n_patch = m0.shape[1]
+        size = self.scaled_patch_size[s]
+        if 2 * size[0] * size[1] * 4 > 64 * 1024 - 256:  # patch image beyond the workgroup's LDS (scale 1 of a large crop)
+            logger.info(f"Scale {s}: patch {size} too large for the batched search, keeping the expanded motion")
+            return m0.reshape(-1)
+        trials = max(1, int(np.ceil(self.opt_config["n_iter"] / (s - self.coarest_scale))))
+        g = int(self.slv_config["patch"].get("search_grid", int(np.ceil(np.sqrt(trials)))))
+        lo, hi = search_box(m0)  # [2, n_patch]
+        u = np.linspace(0.0, 1.0, g) if g > 1 else np.array([0.5])
+        gx = lo[0][:, None] + (hi[0] - lo[0])[:, None] * u[None, :]  # [n_patch, g]
+        gy = lo[1][:, None] + (hi[1] - lo[1])[:, None] * u[None, :]
+        cand = np.stack([np.repeat(gx, g, axis=1), np.tile(gy, (1, g))], axis=-1)  # [n_patch, g*g, 2]
+        cand = np.concatenate([m0.T[:, None, :], cand], axis=1)
+        loss, _, count = handle.patch_search(self.patch_boxes(s), size, cand, self.iwe_config["blur_sigma"])
+        loss = loss.cpu().numpy()
+        loss[~np.isfinite(loss)] = np.inf
+        pick = loss.argmin(axis=1)
+        m1 = cand[np.arange(n_patch), pick].T.copy()  # [2, n_patch]
+        keep = count.cpu().numpy() <= 10
+        m1[:, keep] = m0[:, keep]
+        self.search_history.append((s, cand, loss, pick))
+        return m1.reshape(-1)
 
     def update_coarse_from_fine(self, motion_per_scale: dict) -> dict:
         finest, coarsest = max(motion_per_scale), min(motion_per_scale)

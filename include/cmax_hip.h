@@ -319,6 +319,27 @@ int cmax_patch_plan_evaluate(cmax_patch_plan_t plan, const double *x_host, int w
 int cmax_patch_plan_hvp(cmax_patch_plan_t plan, const double *x_host, const double *v_host, double *hv_host,
                         cmax_stream_t stream);
 
+/* =============================================================================================
+ * Per-patch translation search: the re-initialisation the pyramid solver runs at every scale above
+ * the coarsest.  Replaces the trial loop of initialize_guess_from_optuna_sampling / objective_initial /
+ * calculate_cost_for_small_patch (src/solver/patch_contrast_pyramid.py:320-414): per patch, the events
+ * with x_min <= x < x_max, y_min <= y < y_max (utils.crop_event) are shifted to the patch origin, warped
+ * by a candidate translation to the MIDDLE of the patch's own time span, voted (bilinear) into an
+ * img_h x img_w image, blurred with scipy.ndimage.gaussian_filter(sigma) and scored with the numpy
+ * branch of GradientMagnitude: mean of (Sobel/8)^2 over the whole image, reflect-101 border
+ * (src/costs/gradient_magnitude.py:78-95).  One workgroup per (patch, candidate); every pair of a scale
+ * in one launch.
+ *   boxes     device int32 [n_patch][4] = x_min, x_max, y_min, y_max (rows first), sensor coordinates
+ *   cand      device fp32  [n_patch][n_cand][2] translations, pixel per unit of the RAW timestamps
+ *   gm_out    device fp32  [n_patch][n_cand + 1]: gradient magnitude per candidate; the last column is
+ *             the un-warped patch, so the reference's NormalizedGradientMagnitude loss of candidate c is
+ *             gm_out[p][n_cand] / gm_out[p][c]   (normalized_gradient_magnitude.py:81-94)
+ *   count_out device int32 [n_patch] events inside the box (the reference keeps the incoming motion
+ *             when a patch holds <= 10 events, patch_contrast_pyramid.py:336)
+ * Needs events set on the handle; 2 * img_h * img_w floats must fit 64 KB of LDS.  Asynchronous.  */
+int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h, int img_w, int n_cand,
+                      const float *cand, double sigma, float *gm_out, int *count_out, cmax_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -513,3 +513,57 @@ def gaussian_filter(img, sigma):
     out = np.empty_like(img)
     lib().orc_gaussian_filter(_p(img), img.shape[0], img.shape[1], ctypes.c_double(sigma), _p(out))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# per-patch translation search (pyramid re-initialisation at scales above the coarsest)
+# --------------------------------------------------------------------------------------------
+def gradmag_reflect101(img):
+    """GradientMagnitude.calculate_numpy with omit_boundary False (src/costs/gradient_magnitude.py:78-95), un-signed:
+    mean(gx^2 + gy^2), gx = cv2.Sobel(img, CV_64F, 1, 0, ksize=3) / 8 (derivative along columns), gy = Sobel(0, 1) / 8,
+    OpenCV's default border BORDER_REFLECT_101 (numpy's pad mode 'reflect')."""
+    img = _f64(img)
+    p = np.pad(img, 1, mode="reflect") if min(img.shape) > 1 else np.pad(img, 1, mode="edge")
+    gx = ((p[:-2, 2:] - p[:-2, :-2]) + 2.0 * (p[1:-1, 2:] - p[1:-1, :-2]) + (p[2:, 2:] - p[2:, :-2])) / 8.0
+    gy = ((p[2:, :-2] - p[:-2, :-2]) + 2.0 * (p[2:, 1:-1] - p[:-2, 1:-1]) + (p[2:, 2:] - p[:-2, 2:])) / 8.0
+    return float(np.mean(gx * gx + gy * gy))
+
+
+def crop_event(events, x0, x1, y0, y1):
+    """utils.crop_event (src/utils/event_utils.py:50-70)."""
+    ev = np.asarray(events)
+    m = (x0 <= ev[:, 0]) & (ev[:, 0] < x1) & (y0 <= ev[:, 1]) & (ev[:, 1] < y1)
+    return ev[m]
+
+
+def small_patch_gm(events, box, patch_image_size, theta, sigma):
+    """GM of one patch image for one translation: calculate_cost_for_small_patch's `iwe` leg
+    (src/solver/patch_contrast_pyramid.py:372-414) with objective_initial's scaling (355-370): the candidate is
+    multiplied by the patch's time span and the warper divides dt by the same span, so the displacement is
+    theta * (t - t_mid).  theta None: the un-warped image (`orig_iwe`)."""
+    x0, x1, y0, y1 = (int(v) for v in box)
+    ev = np.array(crop_event(_ev4(events), x0, x1, y0, y1), dtype=np.float64)
+    ev[:, 0] -= x0  # set_event_origin_to_zero (event_utils.py:73-90)
+    ev[:, 1] -= y0
+    if theta is not None and len(ev):
+        t_scale = ev[:, 2].max() - ev[:, 2].min()
+        ev, _ = warp_event(ev, np.asarray(theta, dtype=np.float64) * t_scale, "2d-translation", direction="middle", normalize_t=True)
+    img = vote(ev, patch_image_size, 0, 1.0, eps=1e-8)  # bilinear_vote_numpy floors x + 1e-8
+    if sigma > 0:
+        img = gaussian_filter(img, sigma)
+    return gradmag_reflect101(img), len(ev)
+
+
+def patch_search(events, boxes, patch_image_size, candidates, sigma):
+    """-> (loss [n_patch, n_cand] = GM(orig) / GM(warped), gm [n_patch, n_cand + 1], count [n_patch])."""
+    boxes = np.asarray(boxes).reshape(-1, 4)
+    cands = np.asarray(candidates, dtype=np.float64).reshape(len(boxes), -1, 2)
+    gm = np.zeros((len(boxes), cands.shape[1] + 1))
+    count = np.zeros(len(boxes), dtype=np.int64)
+    for p, box in enumerate(boxes):
+        for c in range(cands.shape[1]):
+            gm[p, c], count[p] = small_patch_gm(events, box, patch_image_size, cands[p, c], sigma)
+        gm[p, -1], count[p] = small_patch_gm(events, box, patch_image_size, None, sigma)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        loss = gm[:, -1:] / gm[:, :-1]
+    return loss, gm, count

@@ -453,6 +453,66 @@ def gen_hvp_cases():
     np.savez_compressed(os.path.join(HERE, "hvp_cases.npz"), **out)
 
 
+def gen_patch_search():
+    """Small-patch cost of the finer-scale re-initialisation: PyramidalPatchContrastMaximization.
+    calculate_cost_for_small_patch on the cropped, origin-shifted events of a patch, called as objective_initial does
+    (src/solver/patch_contrast_pyramid.py:320-414): NormalizedGradientMagnitude on numpy arrays (cv2.Sobel: shim (3))."""
+    from src import solver as ref_solver
+
+    rng = np.random.default_rng(SEED + 5)
+    H, W = 68, 90
+    # moving point features (so that candidates differ in contrast) + uniform noise events
+    n_feat, per_feat, vel, span = 150, 40, np.array([140.0, -90.0]), 0.05
+    p0 = np.stack([rng.uniform(0, H, n_feat), rng.uniform(0, W, n_feat)], axis=1)
+    t = rng.uniform(0, span, (n_feat, per_feat))
+    xy = p0[:, None, :] + vel[None, None, :] * t[..., None]
+    feat = np.concatenate([np.floor(xy.reshape(-1, 2)), t.reshape(-1, 1), np.ones((n_feat * per_feat, 1))], axis=1)
+    feat = feat[(feat[:, 0] >= 0) & (feat[:, 0] < H) & (feat[:, 1] >= 0) & (feat[:, 1] < W)]
+    ev = np.concatenate([feat, make_events(1500, H, W, rng)], axis=0)
+    ev = ev[np.argsort(ev[:, 2], kind="stable")]
+    out = {"image_size": np.array([H, W]), "events": ev, "velocity": vel}
+    slv_cfg = {
+        "method": "pyramidal_patch_contrast_maximization", "time_aware": False,
+        "patch": {"initialize": "random", "scale": 4, "crop_height": 64, "crop_width": 80, "filter_type": "bilinear"},
+        "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
+        "cost": "hybrid", "outer_padding": 0,
+        "cost_with_weight": {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+        "iwe": {"method": "bilinear_vote", "blur_sigma": 1},
+    }
+    opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
+               "parameters": {"trans_x": {"min": -150, "max": 150}, "trans_y": {"min": -150, "max": 150}}}
+    slv = ref_solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
+    for scale in (2, 3):
+        slv.overload_patch_configuration(scale)
+        n_patch, n_cand = slv.n_patch, 6
+        boxes = np.array([[slv.patches[i].x_min, slv.patches[i].x_max, slv.patches[i].y_min, slv.patches[i].y_max]
+                          for i in range(n_patch)])
+        cand = rng.uniform(-250, 250, (n_patch, n_cand, 2))
+        cand[:, 0] = vel  # the true motion
+        cand[:, 1] = 0.0
+        loss = np.zeros((n_patch, n_cand))
+        count = np.zeros(n_patch, dtype=np.int64)
+        for i in range(n_patch):
+            fe = utils.crop_event(ev, *boxes[i])
+            fe = utils.set_event_origin_to_zero(np.copy(fe), boxes[i][0], boxes[i][2], 0)
+            count[i] = len(fe)
+            for c in range(n_cand):
+                if len(fe) == 0:
+                    loss[i, c] = np.nan
+                    continue
+                motion_array = np.array(cand[i, c])
+                motion_array *= np.max(fe[:, 2]) - np.min(fe[:, 2])  # objective_initial, lines 359-361
+                loss[i, c] = slv.calculate_cost_for_small_patch(np.copy(fe), motion_array, "2d-translation")
+        k = f"s{scale}"
+        out[k + "__boxes"] = boxes
+        out[k + "__patch_size"] = np.array(slv.patch_size)
+        out[k + "__cand"] = cand
+        out[k + "__loss"] = loss
+        out[k + "__count"] = count
+    out["sigma"] = np.array(1.0)
+    save("patch_search", **out)
+
+
 def gen_core():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
@@ -467,8 +527,9 @@ def gen_core():
 
 
 if __name__ == "__main__":
-    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp]   (no argument = everything)
-    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp"]
+    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search]   (no argument = everything)
+    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
+                                                                    "patch_search"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -479,3 +540,5 @@ if __name__ == "__main__":
         gen_hvp_cases()
     if "solver_hvp" in which:
         gen_solver_hvp()
+    if "patch_search" in which:
+        gen_patch_search()

@@ -347,3 +347,86 @@ def test_pyramid_solver_end_to_end(time_aware):
     aee = np.sqrt(((flow - V) ** 2).sum(0))[mask].mean()
     aee0 = np.sqrt((V ** 2).sum(0))[mask].mean()
     assert aee < 0.5 * aee0, (aee, aee0)
+
+
+# ---- per-patch translation search (re-initialisation at finer scales) ---------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [2, 3])
+@pytest.mark.parametrize("time_bin", [0, 10])
+def test_patch_search_golden(golden, scale, time_bin):
+    """cmax_patch_search against the reference's calculate_cost_for_small_patch (numpy branch of
+    NormalizedGradientMagnitude) on the fixture's patches and candidates; fp32 votes in 2^-18 fixed point."""
+    g = golden("patch_search")
+    k = f"s{scale}"
+    H, W = (int(v) for v in g["image_size"])
+    handle = E.CMaxHandle((H, W)).set_events(g["events"], time_bin=time_bin)  # un-binned and (tile, bin) order
+    loss, gm, count = handle.patch_search(g[k + "__boxes"], tuple(g[k + "__patch_size"]), g[k + "__cand"], float(g["sigma"]))
+    np.testing.assert_array_equal(count.cpu().numpy(), g[k + "__count"])
+    ref = g[k + "__loss"]
+    got = loss.cpu().numpy()
+    assert np.abs(got / ref - 1.0).max() <= TOL, np.abs(got / ref - 1.0).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma", [0.0, 1.0, 1.6])
+def test_patch_search_ragged_boxes_fractional_events(sigma):
+    """Boxes that are not tile aligned, overlap the sensor border, hold no event or a single event; fractional
+    source coordinates; against the CPU restatement."""
+    rng = np.random.default_rng(5)
+    H, W = 50, 75
+    ev = E.utils.generate_events(6000, H, W, seed=3)
+    ev[:, 0] = np.minimum(ev[:, 0] + rng.uniform(0, 0.999, len(ev)), H - 1e-3)
+    ev[:, 1] = np.minimum(ev[:, 1] + rng.uniform(0, 0.999, len(ev)), W - 1e-3)
+    ev[:, 2] = np.sort(rng.uniform(0.2, 0.26, len(ev)))
+    ev = ev[~((ev[:, 0] >= 30) & (ev[:, 0] < 37) & (ev[:, 1] >= 40) & (ev[:, 1] < 49))]  # an empty box
+    boxes = np.array([[3, 24, 5, 33], [17, 50, 60, 75], [30, 37, 40, 49], [0, 50, 0, 75], [44, 60, 70, 90], [20, 21, 10, 11]])
+    n_cand = 5
+    cand = rng.uniform(-300, 300, (len(boxes), n_cand, 2))
+    for size in [(21, 28), (50, 75)]:
+        handle = E.CMaxHandle((H, W)).set_events(ev)
+        loss, gm, count = handle.patch_search(boxes, size, cand, sigma)
+        loss_o, gm_o, count_o = orc.patch_search(ev, boxes, size, cand, sigma)
+        np.testing.assert_array_equal(count.cpu().numpy(), count_o)
+        got = gm.cpu().numpy()
+        assert np.abs(got - gm_o).max() <= TOL * np.abs(gm_o).max(), (np.abs(got - gm_o).max(), np.abs(gm_o).max())
+        assert (got[count_o == 0] == 0).all()
+
+
+@pytest.mark.gpu
+def test_patch_search_rejects_patch_images_beyond_lds():
+    handle = E.CMaxHandle((64, 64)).set_events(E.utils.generate_events(1000, 64, 64, seed=1))
+    with pytest.raises(RuntimeError, match="LDS"):
+        handle.patch_search([[0, 64, 0, 64]], (128, 168), np.zeros((1, 1, 2)), 1.0)
+
+
+@pytest.mark.gpu
+def test_pyramid_reinitialisation_finds_the_patch_motion(golden):
+    """initialize_guess_from_patch_search on the fixture's scene (point features moving at `velocity`, i.e. the
+    compensating translation is -velocity): from a start 8 % off, the picked candidate of every well-populated
+    patch is the grid point nearest to the truth or a neighbour; the starting point itself is among the candidates,
+    so the picked loss is never above the incoming one."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic import _pyramid_solver
+
+    g = golden("patch_search")
+    slv = _pyramid_solver(n_iter=80)
+    H, W = (int(v) for v in g["image_size"])
+    handle = E.CMaxHandle((H, W)).set_events(g["events"])
+    truth = -g["velocity"]
+    n_patch = slv.scaled_n_patch[2]
+    m0 = np.tile((0.92 * truth)[:, None], (1, n_patch))
+    m1 = slv.initialize_guess_from_patch_search(handle, 2, m0.reshape(-1)).reshape(2, n_patch)
+    s, cand, loss, pick = slv.search_history[-1]
+    assert s == 2 and cand.shape == (n_patch, 1 + 9 * 9, 2) and loss.shape == (n_patch, 82)
+    assert (loss[np.arange(n_patch), pick] <= loss[:, 0]).all()
+    step = (cand[:, -1] - cand[:, 1]) / 8.0  # grid spacing per patch [n_patch, 2]
+    err = np.abs(m1.T - truth[None, :])
+    assert (err <= 1.5 * step).mean() >= 0.85, (err / step)
+    # a patch without enough events keeps the incoming motion
+    few = g["events"][:8].copy()
+    few[:, 0], few[:, 1] = 3.0, 4.0
+    handle2 = E.CMaxHandle((H, W)).set_events(few)
+    np.testing.assert_array_equal(slv.initialize_guess_from_patch_search(handle2, 2, m0.reshape(-1)), m0.reshape(-1))

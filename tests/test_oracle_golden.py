@@ -199,3 +199,16 @@ def test_numpy_branch_blur(golden, sigma):
     size = tuple(int(v) for v in g["image_size"])
     img = orc.vote(g["events"], size, eps=1e-8)
     np.testing.assert_allclose(orc.gaussian_filter(img, sigma), g[f"iwe_numpy_s{sigma}"], rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("scale", [2, 3])
+def test_patch_search_cost(golden, scale):
+    """Per-patch re-initialisation cost (calculate_cost_for_small_patch as objective_initial calls it,
+    src/solver/patch_contrast_pyramid.py:355-414) on cropped, origin-shifted events."""
+    g = golden("patch_search")
+    k = f"s{scale}"
+    loss, gm, count = orc.patch_search(g["events"], g[k + "__boxes"], tuple(g[k + "__patch_size"]), g[k + "__cand"], float(g["sigma"]))
+    np.testing.assert_array_equal(count, g[k + "__count"])
+    np.testing.assert_allclose(loss, g[k + "__loss"], rtol=1e-10)
+    # the un-warped image is candidate 0 px/s: loss exactly 1 (column 1 of the fixture's candidates)
+    np.testing.assert_allclose(loss[:, 1], 1.0, rtol=1e-12)
