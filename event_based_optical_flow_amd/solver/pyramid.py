@@ -187,6 +187,8 @@ class PyramidalPatchContrastMaximization:
             return m0.reshape(-1)
         trials = max(1, int(np.ceil(self.opt_config["n_iter"] / (s - self.coarest_scale))))
         g = int(self.slv_config["patch"].get("search_grid", int(np.ceil(np.sqrt(trials)))))
+        if g <= 0:  # search_grid: 0 switches the re-initialisation off (A/B runs)
+            return m0.reshape(-1)
         lo, hi = search_box(m0)  # [2, n_patch]
         u = np.linspace(0.0, 1.0, g) if g > 1 else np.array([0.5])
         gx = lo[0][:, None] + (hi[0] - lo[0])[:, None] * u[None, :]  # [n_patch, g]

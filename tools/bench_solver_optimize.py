@@ -33,7 +33,7 @@ mask[x.astype(int), y.astype(int)] = True
 mask[:8] = mask[-8:] = False
 mask[:, :8] = mask[:, -8:] = False
 
-for time_aware in (False, True):
+for time_aware, grid in ((False, None), (False, 0), (False, 16), (True, None), (True, 0)):
     slv_cfg = {"method": "pyramidal_patch_contrast_maximization", "time_aware": time_aware,
                "patch": {"initialize": "random", "scale": 5, "crop_height": 256, "crop_width": 336, "filter_type": "bilinear"},
                "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
@@ -44,10 +44,24 @@ for time_aware in (False, True):
         slv_cfg.update({"time_bin": 10, "flow_interpolation": "burgers", "t0_flow_location": "middle"})
     opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
                "parameters": {"trans_x": {"min": -150, "max": 150}, "trans_y": {"min": -150, "max": 150}}}
-    times = []
+    if grid is not None:
+        slv_cfg["patch"]["search_grid"] = grid  # None: the reference's trial budget; 0: no per-patch re-initialisation
+    times, t_search = [], []
     for rep in range(3):
         np.random.seed(46)
         slv = solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
+        inner = slv.initialize_guess_from_patch_search
+
+        def timed(handle, s, m0, inner=inner):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out = inner(handle, s, m0)
+            torch.cuda.synchronize()
+            t_search.append(time.perf_counter() - t1)
+            return out
+
+        slv.initialize_guess_from_patch_search = timed
+        t_search.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         best = slv.optimize(ev)
@@ -59,5 +73,8 @@ for time_aware in (False, True):
     flow = slv.motion_to_dense_flow(best) * t_scale
     aee = np.sqrt(((flow - V) ** 2).sum(0))[mask].mean()
     aee0 = np.sqrt((V ** 2).sum(0))[mask].mean()
-    print("%-8s optimize(): %.3f s (best of 3: %s)  scales %s  f/g/Hv callbacks %d/%d/%d  end-point error %.2f px (zero flow: %.2f px)" % (
-        "burgers" if time_aware else "plain", min(times), ", ".join("%.3f" % t for t in times), sorted(best), nfev, njev, nhev, aee, aee0))
+    n_pairs = sum(c.shape[0] * c.shape[1] for _, c, _, _ in slv.search_history)
+    print("%-8s search_grid %-4s optimize(): %.3f s (best of 3: %s)  scales %s  f/g/Hv callbacks %d/%d/%d  end-point error %.2f px (zero flow: %.2f px)"
+          "  per-patch search: %d (patch, candidate) pairs in %.2f ms over %d scales" % (
+              "burgers" if time_aware else "plain", grid, min(times), ", ".join("%.3f" % t for t in times), sorted(best), nfev, njev, nhev,
+              aee, aee0, n_pairs, 1e3 * sum(t_search), len(t_search)))
