@@ -1410,6 +1410,15 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
     return 0;
 }
 
+// The event kernels read the sorted events in 16-byte pairs, so the pair that holds the last event of the last
+// segment can reach one element past the batch.  That slot is not voted, but its pixel still indexes the flow
+// field (dense / voxel warp): the two padding elements must decode to pixel (0, 0), bin 0 -- not to whatever the
+// allocation held before.
+static int pad_event_tail(cmax_handle_s *h, hipStream_t s) {
+    CMAX_CHECK_HIP(hipMemsetAsync(h->evp + h->n, 0, 2 * sizeof(uint2), s));
+    return 0;
+}
+
 // Re-bin the packed events for h->n_time_bin and re-order them: by (tile, bin) when binned, by tile-major pixel
 // otherwise (see resort_key).  Followed by the work list.
 static int resort_events(cmax_handle_s *h, hipStream_t s) {
@@ -1441,6 +1450,8 @@ static int resort_events(cmax_handle_s *h, hipStream_t s) {
     std::swap(h->rx, h->rx_alt);
     std::swap(h->ry, h->ry_alt);
     std::swap(h->tau64, h->tau64_alt);
+    int rc_pad = pad_event_tail(h, s);
+    if (rc_pad) return rc_pad;
     return build_segments(h, T > 0 ? 1 : 256, s);
 }
 
@@ -1614,6 +1625,8 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     h->long_runs = flags[2] > 0 && h->n >= (int64_t)8 * flags[2];
     h->tmin_host = tmm_host[0];
     h->tmax_host = tmm_host[1];
+    int rc_pad = pad_event_tail(h, s);
+    if (rc_pad) return rc_pad;
     if (n_time_bin > 0) return resort_events(h, s);  // (tile, bin) order + work list
     return build_segments(h, 256, s);
 }

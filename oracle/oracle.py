@@ -300,12 +300,16 @@ _BASE = {"image_variance": variance, "gradient_magnitude": gradmag}
 
 def _base_cost(kind, img, omit):
     """raw contrast + gradient image for kind in {'var','gm'} (torch branch: unbiased var)."""
-    if kind == "var":
-        return variance(img, omit, 1)
-    return gradmag(img, omit)
+    v, G = variance(img, omit, 1) if kind == "var" else gradmag(img, omit)
+    return np.float64(v), G  # IEEE division like the reference's tensors: x/0 = inf, 0/0 = nan (no ZeroDivisionError)
 
 
 def cost_and_image_grads(cost, iwes, omit_boundary=True, direction="minimize", cost_with_weight=None, flow=None):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return _cost_and_image_grads(cost, iwes, omit_boundary, direction, cost_with_weight, flow)
+
+
+def _cost_and_image_grads(cost, iwes, omit_boundary=True, direction="minimize", cost_with_weight=None, flow=None):
     """Evaluate a named cost on a dict of IWEs.  Returns (loss, {key: dL/d iwe_key}, dL/d flow or None).
 
     cost: one of image_variance, gradient_magnitude, normalized_image_variance,
