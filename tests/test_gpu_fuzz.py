@@ -73,3 +73,225 @@ def test_random_configuration_against_oracle(seed):
         assert np.abs(g - ref["grad"]).max() <= tol * gmax, (info, tol, np.abs(g - ref["grad"]).max(), gmax)
     else:
         assert np.abs(g).max() == 0, info
+
+
+# ---- the optimiser's objective (native one-call plan and autograd-chained path) ----------------------------------
+def draw_solver_case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    scale = int(rng.integers(1, 4))
+    crop = (int(rng.choice([32, 48, 64])), int(rng.choice([32, 64, 80])))
+    H, W = crop[0] + int(rng.integers(0, 7)), crop[1] + int(rng.integers(0, 11))
+    psize = (crop[0] // 2 ** scale, crop[1] // 2 ** scale)
+    pis = (len(np.arange(0, crop[0], psize[0])), len(np.arange(0, crop[1], psize[1])))
+    shift = ((H - crop[0]) // 2, (W - crop[1]) // 2)
+    n = int(rng.choice([40, 800, 6000]))
+    vel = rng.uniform(-6, 6, 2)
+    ev = E.utils.generate_structured_events(n, H, W, tuple(vel), n_dots=max(3, n // 50), seed=seed, tmin=1.0, tmax=1.0 + float(rng.choice([0.02, 0.5])))
+    t_scale = ev[:, 2].max() - ev[:, 2].min()
+    x = (rng.uniform(-1, 1, (2,) + pis) * 2.0 + vel[:, None, None]) / t_scale  # pixel / time unit
+    time_aware = bool(seed % 2)
+    cost = str(rng.choice(["hybrid", "hybrid", "image_variance", "multi_focal_normalized_image_variance"]))
+    cww = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": float(rng.choice([0.01, 0.3]))} if cost == "hybrid" else None
+    return dict(H=H, W=W, ev=ev, x=x.reshape(-1), pis=pis, psize=psize, shift=shift, time_aware=time_aware, cost=cost, cww=cww,
+                sigma=int(rng.integers(0, 2)), T=int(rng.choice([2, 5, 10])), scheme=str(rng.choice(["burgers", "upwind"])),
+                t0=str(rng.choice(["first", "middle"])), t_scale=t_scale)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CMAX_FUZZ_SEEDS", "24"))))
+def test_random_solver_objective_against_oracle(seed):
+    from event_based_optical_flow_amd.solver import PatchFlowObjective
+    from event_based_optical_flow_amd.solver.scipy_autograd import TorchWrapper
+
+    c = draw_solver_case(seed)
+    size = (c["H"], c["W"])
+    ref_loss, ref_grad = orc.solver_objective(c["ev"], c["x"], size, c["pis"], c["psize"], c["psize"], c["shift"], cost=c["cost"],
+                                              cost_with_weight=c["cww"], sigma=c["sigma"], time_aware=c["time_aware"], time_bin=c["T"],
+                                              flow_interpolation=c["scheme"], t0_flow_location=c["t0"])
+    h = E.CMaxHandle(size).set_events(c["ev"], time_bin=c["T"] if c["time_aware"] else 0)
+    obj = PatchFlowObjective(h, c["t_scale"], c["pis"], c["psize"], c["psize"], c["shift"], cost=c["cost"], cost_with_weight=c["cww"],
+                             blur_sigma=c["sigma"], time_aware=c["time_aware"], time_bin=c["T"], flow_interpolation=c["scheme"],
+                             t0_flow_location=c["t0"])
+    info = {k: c[k] for k in ("H", "W", "pis", "psize", "shift", "time_aware", "cost", "sigma", "T", "scheme", "t0")}
+    assert obj.has_native_plan, info
+    gmax = np.abs(ref_grad).max()
+    for path in ("native", "native again", "autograd"):
+        w = TorchWrapper(obj, precision="float64")
+        w.force_autograd = path == "autograd"
+        w.get_input(c["x"])
+        loss, grad = w.get_value_and_grad(c["x"])
+        assert abs(loss - ref_loss) <= 2e-4 * abs(ref_loss), (path, info, loss, ref_loss)
+        err = np.abs(grad - ref_grad)
+        # a cell-border event (fp32 floor, see above) shows up in the few patches that see its pixel
+        assert (err > 2e-4 * gmax).sum() <= 4 and err.max() <= 2e-2 * gmax, (path, info, err.max(), gmax)
+    # exact Hessian-vector products: finite, and the Hessian they come from is symmetric (<u, H v> = <v, H u>)
+    rng = np.random.default_rng(seed)
+    u, v = rng.normal(size=c["x"].size), rng.normal(size=c["x"].size)
+    hu, hv = obj.hvp_numpy(c["x"], u), obj.hvp_numpy(c["x"], v)
+    assert np.isfinite(hu).all() and np.isfinite(hv).all(), info
+    a, b = float(v @ hu), float(u @ hv)
+    assert abs(a - b) <= 2e-3 * max(abs(a), abs(b)) + 2e-4 * min(np.abs(v * hu).sum(), np.abs(u * hv).sum()), (info, a, b)
+
+
+# ---- one long-lived handle fed different batches, time bins and models in sequence --------------------------------
+def test_one_handle_many_batches():
+    rng = np.random.default_rng(77)
+    H, W = 57, 83
+    h = E.CMaxHandle((H, W), 2)
+    for it in range(40):
+        n = int(rng.choice([3, 50, 700, 9000, 60000]))
+        T = int(rng.choice([0, 0, 1, 4, 10]))
+        vel = rng.uniform(-8, 8, 2)
+        ev = E.utils.generate_structured_events(n, H, W, tuple(vel), n_dots=max(3, n // 70), seed=it)
+        if rng.random() < 0.3:
+            ev[:, 0] = np.minimum(ev[:, 0] + rng.uniform(0, 0.99, n), H - 1e-3)
+        h.set_events(ev, time_bin=T)
+        for rep in range(int(rng.integers(1, 4))):
+            if T > 0 and rng.random() < 0.7:
+                model, motion = "dense-flow-voxel", np.stack([-(E.utils.generate_smooth_flow((H, W), 3.0, seed=it + k) + vel[:, None, None]) for k in range(T)])
+            elif rng.random() < 0.5:
+                model, motion = "dense-flow", -(E.utils.generate_smooth_flow((H, W), 3.0, seed=it) + vel[:, None, None])
+            else:
+                model, motion = "2d-translation", vel * rng.uniform(0.6, 1.2)
+            cost = str(rng.choice(COSTS))
+            sigma = int(rng.integers(0, 2))
+            ref = orc.objective(ev, motion, model, (H, W), cost=cost, sigma=sigma, outer_padding=2)
+            obj = E.ContrastObjective(h, model, cost=cost, sigma=sigma)
+            m = torch.as_tensor(np.ascontiguousarray(motion), dtype=torch.float64, device="cuda").requires_grad_()
+            loss = obj(m)
+            (g,) = torch.autograd.grad(loss, m)
+            info = (it, rep, n, T, model, cost, sigma)
+            assert abs(loss.item() - ref["loss"]) <= 3e-4 * abs(ref["loss"]), (info, loss.item(), ref["loss"])
+            gmax = np.abs(ref["grad"]).max()
+            err = np.abs(g.cpu().numpy() - ref["grad"])
+            # at most a handful of cell-border events (fp32 floor) may differ by a whole vote
+            assert (err > 3e-4 * gmax).sum() <= 8 and err.max() <= 5e-2 * gmax, (info, err.max(), gmax, int((err > 3e-4 * gmax).sum()))
+        if T == 0 and rng.random() < 0.5:  # re-bin the same batch in place
+            h.set_time_bins(int(rng.choice([2, 6])))
+            T2 = h.time_bin
+            motion = np.stack([-(E.utils.generate_smooth_flow((H, W), 2.0, seed=it) + vel[:, None, None])] * T2)
+            ref = orc.objective(ev, motion, "dense-flow-voxel", (H, W), cost="image_variance", sigma=0, outer_padding=2)
+            loss = E.ContrastObjective(h, "dense-flow-voxel", cost="image_variance", sigma=0)(torch.as_tensor(motion, device="cuda"))
+            assert abs(loss.item() - ref["loss"]) <= 3e-4 * abs(ref["loss"]), (it, "rebinned", loss.item(), ref["loss"])
+
+
+# ---- per-patch search on random boxes ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(8))
+def test_random_patch_search_against_oracle(seed):
+    rng = np.random.default_rng(900 + seed)
+    H, W = int(rng.integers(20, 100)), int(rng.integers(20, 130))
+    n = int(rng.choice([30, 2000, 20000]))
+    ev = E.utils.generate_structured_events(n, H, W, (7.0, -4.0), n_dots=max(3, n // 40), seed=seed, tmin=2.0, tmax=2.04)
+    if seed % 2:
+        ev[:, 1] = np.minimum(ev[:, 1] + rng.uniform(0, 0.99, n), W - 1e-3)
+    n_patch, n_cand = int(rng.integers(1, 12)), int(rng.integers(1, 9))
+    x0, y0 = rng.integers(-4, H - 4, n_patch), rng.integers(-4, W - 4, n_patch)
+    boxes = np.stack([x0, x0 + rng.integers(1, 40, n_patch), y0, y0 + rng.integers(1, 50, n_patch)], axis=1)
+    size = (int(rng.integers(8, 60)), int(rng.integers(8, 80)))
+    cand = rng.uniform(-400, 400, (n_patch, n_cand, 2))
+    sigma = float(rng.choice([0.0, 1.0, 2.0]))
+    h = E.CMaxHandle((H, W)).set_events(ev, time_bin=int(rng.choice([0, 5])))
+    loss, gm, count = h.patch_search(boxes, size, cand, sigma)
+    loss_o, gm_o, count_o = orc.patch_search(ev, boxes, size, cand, sigma)
+    np.testing.assert_array_equal(count.cpu().numpy(), count_o)
+    err = np.abs(gm.cpu().numpy() - gm_o)
+    assert err.max() <= 2e-4 * max(gm_o.max(), 1e-12), (H, W, n, size, sigma, err.max(), gm_o.max())
+
+
+# ---- leaf operators on random shapes, fp64 and fp32 ----------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("seed", range(12))
+def test_random_leaf_operators_against_oracle(seed, dtype):
+    from event_based_optical_flow_amd import functional as F
+
+    rng = np.random.default_rng(300 + seed)
+    H, W = int(rng.integers(3, 70)), int(rng.integers(3, 90))
+    pad = int(rng.choice([0, 0, 2]))
+    n = int(rng.choice([1, 5, 400, 12000]))
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    ev = E.utils.generate_events(n, H, W, tmin=0.1, tmax=0.4, seed=seed)
+    if seed % 2:
+        ev[:, 0] = np.minimum(ev[:, 0] + rng.uniform(0, 0.99, n), H - 1e-3)
+        ev[:, 1] = np.minimum(ev[:, 1] + rng.uniform(0, 0.99, n), W - 1e-3)
+    if dtype == torch.float32:
+        ev = ev.astype(np.float32).astype(np.float64)  # identical inputs for both sides
+    t_ev = torch.as_tensor(ev, dtype=dtype, device="cuda")
+
+    def close(got, ref, what, scale=None):
+        got, ref = np.asarray(got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got, dtype=np.float64), np.asarray(ref)
+        s = np.abs(ref).max() if scale is None else scale
+        assert np.abs(got - ref).max() <= tol * max(s, 1e-30), (what, H, W, pad, n, np.abs(got - ref).max(), s)
+
+    # warps (all three models, a random reference time)
+    direction = [0.0, 0.5, 1.0, 0.27][seed % 4]
+    dname = {0.0: "first", 0.5: "middle", 1.0: "last"}.get(direction, direction)
+    theta = rng.uniform(-9, 9, 2)
+    flow = rng.uniform(-9, 9, (2, H, W))
+    T = int(rng.choice([1, 4]))
+    voxel = rng.uniform(-9, 9, (T, 2, H, W))
+    warped = None
+    if n > 1:
+        for model, motion in (("2d-translation", theta), ("dense-flow", flow), ("dense-flow-voxel", voxel)):
+            ref, _ = orc.warp_event(ev, motion, model, dname, (H, W))
+            got = F.warp_events(t_ev, torch.as_tensor(motion, dtype=dtype, device="cuda"), model, (H, W), dname, normalize_t=True)
+            close(got[:, :3], ref[:, :3], "warp " + model, scale=max(H, W))
+        warped = ref
+    # votes (with padding, per-event weights; fp32 compared on warped coordinates rounded to fp32)
+    pts = (warped if warped is not None else ev).copy()
+    if dtype == torch.float32:
+        pts = pts.astype(np.float32).astype(np.float64)
+    wts = rng.uniform(0.2, 2.0, n)
+    if dtype == torch.float32:
+        wts = wts.astype(np.float32).astype(np.float64)
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    ref_img = orc.vote(pts, (H, W), pad, weight=wts, eps=1e-6)
+    got_img = F.vote(torch.as_tensor(pts, dtype=dtype, device="cuda"), (Hp, Wp), (pad, pad), weight=torch.as_tensor(wts, dtype=dtype, device="cuda"))
+    if dtype == torch.float64:
+        close(got_img, ref_img, "vote")
+    else:  # the fp32 floor may move a border event by one cell
+        err = np.abs(got_img.cpu().numpy() - ref_img)
+        assert (err > 2e-4 * max(ref_img.max(), 1e-30)).sum() <= 8, ("vote fp32", H, W, n)
+    # blur, contrast values and image gradients, total variation
+    img = rng.uniform(0, 5, (Hp, Wp))
+    if dtype == torch.float32:
+        img = img.astype(np.float32).astype(np.float64)
+    t_img = torch.as_tensor(img, dtype=dtype, device="cuda")
+    sigma = float(rng.choice([0.5, 1.0, 2.5]))
+    close(F.gaussian_blur3(t_img, sigma), orc.blur3(img, sigma), "blur3")
+    for omit in (False, True):
+        if omit and min(Hp, Wp) <= 2:
+            continue
+        for cost_id, fn in ((0, lambda a, o: orc.variance(a, o, 1)), (1, orc.gradmag)):
+            v_ref, G_ref = fn(img, omit)
+            if not np.isfinite(v_ref):
+                continue
+            ti = t_img.clone().requires_grad_()
+            v = F.contrast(ti, cost_id, omit)
+            (G,) = torch.autograd.grad(v, ti)
+            assert abs(v.item() - v_ref) <= tol * max(abs(v_ref), 1e-30), ("contrast", cost_id, omit, Hp, Wp, v.item(), v_ref)
+            close(G, G_ref, f"contrast grad {cost_id} {omit}")
+    if min(H, W) > 2:
+        fl = rng.uniform(-3, 3, (2, H, W))
+        if dtype == torch.float32:
+            fl = fl.astype(np.float32).astype(np.float64)
+        tf = torch.as_tensor(fl, dtype=dtype, device="cuda").requires_grad_()
+        for omit in (False, True):
+            v_ref, G_ref = orc.total_variation(fl, omit)
+            v = F.total_variation(tf, omit)
+            (G,) = torch.autograd.grad(v, tf)
+            assert abs(v.item() - v_ref) <= tol * abs(v_ref), ("tv", omit, H, W)
+            close(G, G_ref, "tv grad")
+        # Burgers / upwind propagation and the voxel chain with its adjoint
+        for scheme, step, step_adj in (("burgers", orc.burgers_step, orc.burgers_step_adj), ("upwind", orc.upwind_step, orc.upwind_step_adj)):
+            dt = float(rng.choice([-0.1, 0.1, 0.25]))
+            close(F.flow_step(tf.detach(), dt, scheme), step(fl, dt), scheme + " step")
+            Tb = int(rng.choice([1, 2, 5]))
+            t0 = str(rng.choice(["first", "middle"]))
+            V_ref = orc.construct_dense_flow_voxel(fl, Tb, scheme, t0)
+            tf2 = tf.detach().clone().requires_grad_()
+            V = F.construct_dense_flow_voxel(tf2, Tb, scheme, t0)
+            close(V, V_ref, scheme + " voxel")
+            gV = rng.uniform(-1, 1, V_ref.shape)
+            if dtype == torch.float32:
+                gV = gV.astype(np.float32).astype(np.float64)
+            (gF,) = torch.autograd.grad(V, tf2, grad_outputs=torch.as_tensor(gV, dtype=dtype, device="cuda"))
+            close(gF, orc.construct_dense_flow_voxel_adj(V_ref, gV, scheme, t0), scheme + " voxel adjoint")
