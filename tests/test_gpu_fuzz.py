@@ -295,3 +295,46 @@ def test_random_leaf_operators_against_oracle(seed, dtype):
                 gV = gV.astype(np.float32).astype(np.float64)
             (gF,) = torch.autograd.grad(V, tf2, grad_outputs=torch.as_tensor(gV, dtype=dtype, device="cuda"))
             close(gF, orc.construct_dense_flow_voxel_adj(V_ref, gV, scheme, t0), scheme + " voxel adjoint")
+
+
+# ---- non-finite / absurd inputs must neither fault nor poison the handle ---------------------------------------------------
+@pytest.mark.parametrize("model", MODELS)
+def test_non_finite_inputs_do_not_poison_the_handle(model):
+    rng = np.random.default_rng(4)
+    H, W, T = 45, 61, 4
+    ev = E.utils.generate_structured_events(8000, H, W, (5.0, -3.0), n_dots=150, seed=2)
+    bad = ev.copy()
+    bad[::97, 0] = np.nan
+    bad[5::131, 1] = np.inf
+    bad[7::151, 2] = np.nan
+    bad[11::173, 0] = -1e30
+    bad[13::191, 1] = 1e30
+    tb = T if model == "dense-flow-voxel" else 0
+    h = E.CMaxHandle((H, W)).set_events(ev, time_bin=tb)
+    shape = {"2d-translation": (2,), "dense-flow": (2, H, W), "dense-flow-voxel": (T, 2, H, W)}[model]
+    good = -np.broadcast_to(np.array([5.0, -3.0]).reshape((2,) + (1,) * (len(shape) - 1) if model != "dense-flow-voxel" else (1, 2, 1, 1)), shape).copy()
+    if model == "2d-translation":
+        good = -good
+    ref = orc.objective(ev, good, model, (H, W), cost="gradient_magnitude", sigma=1)
+
+    def run(motion, handle=h):
+        obj = E.ContrastObjective(handle, model, cost="gradient_magnitude", sigma=1)
+        m = torch.as_tensor(np.ascontiguousarray(motion), dtype=torch.float64, device="cuda").requires_grad_()
+        loss = obj(m)
+        (g,) = torch.autograd.grad(loss, m)
+        torch.cuda.synchronize()
+        return loss.item(), g.cpu().numpy()
+
+    for poison in (np.nan, np.inf, -np.inf, 1e30, -3e38, 1e-40):
+        m = good.copy()
+        m.reshape(-1)[:: max(1, m.size // 7)] = poison
+        run(m)  # value is meaningless; it must come back
+        loss, g = run(good)
+        assert abs(loss - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (poison, loss, ref["loss"])
+        assert np.abs(g - ref["grad"]).max() <= 1e-4 * np.abs(ref["grad"]).max(), poison
+    # a batch with non-finite coordinates / timestamps: those events are dropped or harmless, the rest is evaluated
+    h2 = E.CMaxHandle((H, W)).set_events(bad, time_bin=tb)
+    run(good, h2)
+    h2.set_events(ev, time_bin=tb)
+    loss, g = run(good, h2)
+    assert abs(loss - ref["loss"]) <= 1e-4 * abs(ref["loss"])
