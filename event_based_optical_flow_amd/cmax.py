@@ -92,6 +92,8 @@ class CMaxHandle:
             pass
 
     # ------------------------------------------------------------------------------------------
+    finds_time_extremes = True  # set_events(ev, None, None, ...) reduces t_min / t_max on the device
+
     def set_events(self, events, tmin: Optional[float] = None, tmax: Optional[float] = None, time_bin: int = 0):
         """Pack + sort one [n,4] batch (numpy or tensor, fp32/fp64).  (tmin, tmax): global batch
         extremes when this handle only holds a time slice of the batch (multi-GPU)."""

@@ -9,8 +9,8 @@ dL/dIWE.  Per objective evaluation there are exactly two exchange steps:
     C2  all-reduce(sum) of the gradient          double[2] | fp32 [2,H,W] | fp32 [T,2,H,W]
 
 Between them every rank redundantly evaluates the (image-space, microseconds) contrast on the
-reduced image, which avoids a broadcast.  t_min / t_max are agreed once per batch with a MIN/MAX
-all-reduce because dt normalisation and the voxel bin edges are defined on the whole batch
+reduced image, which avoids a broadcast.  t_min / t_max are agreed once per batch with one MIN
+all-reduce over (t_min, -t_max) because dt normalisation and the voxel bin edges are defined on the whole batch
 (src/warp.py:216-224, 254-259, 342-345).
 
 The per-rank compute is injected (`local`): production uses CMaxHandle (HIP); the CPU test
@@ -32,13 +32,13 @@ def time_slice_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 def agree_time_extremes(t_local_min: float, t_local_max: float, group=None, device="cpu") -> Tuple[float, float]:
-    """Global (t_min, t_max) of the batch from per-slice extremes (one MIN + one MAX all-reduce)."""
-    lo = torch.tensor([t_local_min], dtype=torch.float64, device=device)
-    hi = torch.tensor([t_local_max], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    return float(lo.item()), float(hi.item())
+    """Global (t_min, t_max) of the batch from per-slice extremes: ONE all-reduce, MIN over (t_min, -t_max)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return float(t_local_min), float(t_local_max)
+    pair = torch.tensor([t_local_min, -t_local_max], dtype=torch.float64, device=device)
+    dist.all_reduce(pair, op=dist.ReduceOp.MIN, group=group)
+    lo, neg_hi = pair.tolist()
+    return float(lo), float(-neg_hi)
 
 
 class TimeSlicedObjective:
@@ -61,6 +61,10 @@ class TimeSlicedObjective:
     def set_local_events(self, events_slice, time_bin: int = 0, device="cpu"):
         """`events_slice`: this rank's contiguous time slice [n_local, 4] (may be empty)."""
         ev = events_slice
+        if self.world_size == 1 and getattr(self.local, "finds_time_extremes", False):
+            # the whole batch is here: the handle reduces t_min / t_max on the device, no host round trip
+            self.local.set_events(ev, None, None, time_bin)
+            return None, None
         if len(ev) > 0:
             t = ev[:, 2]
             lo, hi = float(t.min()), float(t.max())
