@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # CMAX_LIB: alternative output / load path (tuning experiments build variants side by side)
 LIB_PATH = os.environ.get("CMAX_LIB", os.path.join(PKG_DIR, "libcmax_hip.so"))
 SOURCES = ["cmax_leaf.hip", "cmax_flow.hip", "cmax_fused.hip", "cmax_solver.hip"]
-HEADERS = ["cmax_common.h", "cmax_image_kernels.h", "cmax_patch_kernels.h", "cmax_flow_dual.h", "cmax_search_kernels.h", "cmax_event_kernels.inc", os.path.join("..", "..", "include", "cmax_hip.h")]
+HEADERS = ["cmax_common.h", "cmax_image_kernels.h", "cmax_patch_kernels.h", "cmax_flow_dual.h", "cmax_search_kernels.h", "cmax_sort_kernels.h", "cmax_event_kernels.inc", os.path.join("..", "..", "include", "cmax_hip.h")]
 # -munsafe-fp-atomics: fp32/fp64 atomicAdd lower to global_atomic_add_f32/_f64 and ds_add_f32
 # (hardware atomics) instead of compare-and-swap loops.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",

@@ -38,6 +38,7 @@
 #include "cmax_common.h"
 #include "cmax_image_kernels.h"
 #include "cmax_search_kernels.h"
+#include "cmax_sort_kernels.h"
 
 namespace cmax {
 
@@ -101,15 +102,14 @@ struct cmax_handle_s {
     uint2 *evp = nullptr;  // packed events, 8 B each, 16-byte aligned base (+2 elements of padding)
     float *rx = nullptr, *ry = nullptr;
     double *tau64 = nullptr;
-    // second set for re-ordering by (tile, time bin) (binned handles only; swapped with the first after a re-sort)
+    // staging SoA of the two-level sort (tile buckets before the per-tile ordering)
     uint2 *evp_alt = nullptr;
     float *rx_alt = nullptr, *ry_alt = nullptr;
     double *tau64_alt = nullptr;
     int64_t cap_alt = 0;
     // sort scratch
-    uint32_t *key_tmp = nullptr;
-    int *counts = nullptr;  // [nkeys + 1] -> offsets after the scan
-    int *cursor = nullptr;  // [nkeys]
+    int *counts = nullptr;  // [nkeys + 1] events per tile -> tile offsets after the scan
+    int *cursor = nullptr;  // [nkeys] per-tile cursor of the bucket pass, then active source pixels per tile
     int *scan_tmp = nullptr;  // [ceil(nkeys / 2048)] chunk sums of the scan
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] source pixels with >= 1 event
@@ -202,43 +202,11 @@ static void dev_free(T **p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// set_events: pack + counting sort by source tile
+// set_events: pack + two-level sort (cmax_sort_kernels.h); the scan of the tile counts lives here
 // ---------------------------------------------------------------------------------------------
 __global__ void k_tmm_set(double *tmm, double lo, double hi) {
     tmm[0] = lo;
     tmm[1] = hi;
-}
-
-__device__ __forceinline__ int voxel_bin(double tau, int T) {
-    // reference edges for direction "first": e_k = k/T * (dtmax - dtmin) + dtmin with dt in [0,1]
-    // (src/warp.py:342-345); the event belongs to the last k with e_k <= dt.
-    int k = (int)(tau * (double)T);
-    if (k > T - 1) k = T - 1;
-    if (k < 0) k = 0;
-    while (k > 0 && ((double)k / (double)T) > tau) --k;
-    while (k + 1 < T && ((double)(k + 1) / (double)T) <= tau) ++k;
-    return k;
-}
-
-// pass 1: sort key per event + histogram
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_pack_hist(const T *__restrict__ ev, int64_t n, int H, int W, int ntc, uint32_t *__restrict__ key, int *__restrict__ counts,
-            int *__restrict__ flags) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        T x = ev[4 * i + 0], y = ev[4 * i + 1];
-        T fx = floor_t<T>(x), fy = floor_t<T>(y);
-        uint32_t k = kDropped;
-        if (fx >= (T)0 && fx < (T)H && fy >= (T)0 && fy < (T)W) {  // NaN fails every comparison -> dropped
-            int ix = (int)fx, iy = (int)fy;
-            k = (uint32_t)(((ix / kTile) * ntc + (iy / kTile)) * (kTile * kTile) + (ix % kTile) * kTile + (iy % kTile));
-            atomicAdd(&counts[k], 1);
-            if (x != fx || y != fy) flags[0] = 1;
-        } else {
-            atomicAdd(&flags[1], 1);
-        }
-        key[i] = k;
-    }
 }
 
 // Exclusive scan of counts[0..m) in place, counts[m] = total, in three small launches: sums of 2048-element
@@ -322,75 +290,6 @@ __global__ void __launch_bounds__(256) k_scan_apply(int *__restrict__ counts, in
     for (int u = 0; u < 8; ++u) {
         if (base + u < m) counts[base + u] = run;
         run += c[u];
-    }
-}
-
-// pass 2: scatter into the sorted, packed SoA
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_scatter(const T *__restrict__ ev, int64_t n, const uint32_t *__restrict__ key, const int *__restrict__ offsets,
-          int *__restrict__ cursor, const double *__restrict__ tmm, int n_time_bin, uint2 *__restrict__ evp,
-          float *__restrict__ rx, float *__restrict__ ry, double *__restrict__ tau64) {
-    const double tmin = tmm[0], per = tmm[1] - tmm[0];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t k = key[i];
-        if (k == kDropped) continue;
-        int pos = offsets[k] + atomicAdd(&cursor[k], 1);
-        T x = ev[4 * i + 0], y = ev[4 * i + 1];
-        T fx = floor_t<T>(x), fy = floor_t<T>(y);
-        double tn = per > 0 ? ((double)ev[4 * i + 2] - tmin) / per : 0.0;
-        uint32_t bin = n_time_bin > 0 ? (uint32_t)voxel_bin(tn, n_time_bin) : 0u;
-        evp[pos] = make_uint2((uint32_t)(int)fx | ((uint32_t)(int)fy << 12) | (bin << 24), __float_as_uint((float)tn));
-        rx[pos] = (float)(x - fx);
-        ry[pos] = (float)(y - fy);
-        tau64[pos] = tn;
-    }
-}
-
-// first sorted event of every group: offsets[] holds one entry per sort key, a group = `stride` consecutive keys
-// (256 pixel keys of a source tile, or one (tile, time bin) key)
-__global__ void __launch_bounds__(256) k_group_starts(const int *__restrict__ offsets, int ngroups, int stride, int *__restrict__ group_start) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g <= ngroups) group_start[g] = offsets[(int64_t)g * stride];
-}
-
-// Re-order the packed events for a (new) number of time bins.
-//   T > 0 : key = tile * T + bin.  The voxel model accumulates flow gradients per (pixel, bin) cell in LDS; with
-//           the events of a tile grouped by bin a workgroup touches 1-4 bins instead of all T, so its accumulator
-//           flush is T/3 times denser (cfg4 K3 26 -> see profiles), and neighbouring lanes hit different pixels
-//           (no same-address LDS atomics).  Pixel order inside a group is not needed by that path.
-//   T == 0: tile-major pixel key (the dense model's segmented scan wants equal pixels adjacent).
-__device__ __forceinline__ uint32_t resort_key(uint32_t pk, int T, int ntc) {
-    const int ix = (int)(pk & 0xFFFu), iy = (int)((pk >> 12) & 0xFFFu);
-    const int tile = (ix / kTile) * ntc + (iy / kTile);
-    if (T > 0) return (uint32_t)(tile * T) + (pk >> 24);
-    return (uint32_t)(tile * (kTile * kTile) + (ix % kTile) * kTile + (iy % kTile));
-}
-
-__global__ void __launch_bounds__(256)
-k_rekey_hist(int64_t n, const double *__restrict__ tau64, int T, int ntc, uint2 *__restrict__ evp, uint32_t *__restrict__ key,
-             int *__restrict__ counts) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t bin = T > 0 ? (uint32_t)voxel_bin(tau64[i], T) : 0u;
-        const uint32_t pk = (evp[i].x & 0x00FFFFFFu) | (bin << 24);
-        evp[i].x = pk;
-        const uint32_t k = resort_key(pk, T, ntc);
-        key[i] = k;
-        atomicAdd(&counts[k], 1);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-k_rescatter(int64_t n, const uint32_t *__restrict__ key, const int *__restrict__ offsets, int *__restrict__ cursor,
-            const uint2 *__restrict__ evp, const float *__restrict__ rx, const float *__restrict__ ry, const double *__restrict__ tau64,
-            uint2 *__restrict__ evp2, float *__restrict__ rx2, float *__restrict__ ry2, double *__restrict__ tau2) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t k = key[i];
-        const int pos = offsets[k] + atomicAdd(&cursor[k], 1);
-        evp2[pos] = evp[i];
-        rx2[pos] = rx[i];
-        ry2[pos] = ry[i];
-        tau2[pos] = tau64[i];
     }
 }
 
@@ -1337,6 +1236,23 @@ static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, 
     return 0;
 }
 
+// The event kernels read the sorted events in 16-byte pairs, so the pair that holds the last event of the last
+// segment can reach one element past the batch.  That slot is not voted, but its pixel still indexes the flow
+// field (dense / voxel warp): the two padding elements must decode to pixel (0, 0), bin 0 -- not to whatever the
+// allocation held before.
+static int pad_event_tail(cmax_handle_s *h, hipStream_t s) {
+    CMAX_CHECK_HIP(hipMemsetAsync(h->evp + h->n, 0, 2 * sizeof(uint2), s));
+    return 0;
+}
+
+// host copy of what one batch left on the device: [0] any fractional source coordinate, [1] dropped events,
+// [2] source pixels with >= 1 event (un-binned order only); batch time extremes
+struct BatchReadback {
+    int flags[4] = {0, 0, 0, 0};
+    double tmm[2] = {0.0, 0.0};
+    int64_t n_in = 0;
+};
+
 // Work list of the event kernels from the sorted events.  counts[] = exclusive scan of the sort-key histogram;
 // a GROUP = `stride` consecutive keys = one source tile (pixel keys) or one (tile, time bin).
 // Segments: <= kSegMax consecutive sorted events (fixed-point range) inside one tile row, spanning <= 12 groups
@@ -1346,14 +1262,32 @@ static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, 
 //   * smaller batches are latency-bound: small groups are merged while they fit, a group with more than
 //     kSegMax events is split into EQUAL parts -- group-aligned windows are tighter and no workgroup is left
 //     with a small remainder (cfg2: 2040 + 806 per tile -> 2 x 1423).
-static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
+static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchReadback *rb = nullptr) {
     const int T = stride == 1 ? h->n_time_bin : 1;  // groups per tile
     const int ngroups = h->ntr * h->ntc * T;
-    hipLaunchKernelGGL(k_group_starts, dim3(div_up(ngroups + 1, 256)), dim3(256), 0, s, h->counts, ngroups, stride, h->d_tile_start);
-    CMAX_CHECK_LAUNCH();
     std::vector<int> group_start((size_t)ngroups + 1);
     CMAX_CHECK_HIP(hipMemcpyAsync(group_start.data(), h->d_tile_start, group_start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<int> tile_active;
+    if (rb) {  // what the host needs to know about the batch rides on the same synchronisation
+        if (T == 1 && h->n_time_bin == 0) {
+            tile_active.resize((size_t)h->ntr * h->ntc);
+            CMAX_CHECK_HIP(hipMemcpyAsync(tile_active.data(), h->cursor, tile_active.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        }
+        CMAX_CHECK_HIP(hipMemcpyAsync(rb->flags, h->d_flags, sizeof(rb->flags), hipMemcpyDeviceToHost, s));
+        CMAX_CHECK_HIP(hipMemcpyAsync(rb->tmm, h->d_tmm, sizeof(rb->tmm), hipMemcpyDeviceToHost, s));
+    }
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
+    if (rb) {
+        h->has_frac = rb->flags[0] != 0;
+        h->n = rb->n_in - rb->flags[1];
+        int64_t active = 0;  // source pixels that hold events (un-binned order)
+        for (int a : tile_active) active += a;
+        h->long_runs = active > 0 && h->n >= 8 * active;
+        h->tmin_host = rb->tmm[0];
+        h->tmax_host = rb->tmm[1];
+        int rc = pad_event_tail(h, s);
+        if (rc) return rc;
+    }
     const int max_groups = kAccCells / 256;
     const bool free_cut = h->n > (int64_t)1024 * kSegMax;
     // batches far below one full segment per CU (the solver's 30k-event slices): a workgroup walks its events
@@ -1410,21 +1344,12 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s) {
     return 0;
 }
 
-// The event kernels read the sorted events in 16-byte pairs, so the pair that holds the last event of the last
-// segment can reach one element past the batch.  That slot is not voted, but its pixel still indexes the flow
-// field (dense / voxel warp): the two padding elements must decode to pixel (0, 0), bin 0 -- not to whatever the
-// allocation held before.
-static int pad_event_tail(cmax_handle_s *h, hipStream_t s) {
-    CMAX_CHECK_HIP(hipMemsetAsync(h->evp + h->n, 0, 2 * sizeof(uint2), s));
-    return 0;
-}
-
-// Re-bin the packed events for h->n_time_bin and re-order them: by (tile, bin) when binned, by tile-major pixel
-// otherwise (see resort_key).  Followed by the work list.
-static int resort_events(cmax_handle_s *h, hipStream_t s) {
-    const int64_t n = h->n;
-    const int T = h->n_time_bin;
-    if (h->cap_alt < h->cap) {
+// Order `n_in` events from `src` for h->n_time_bin (cmax_sort_kernels.h) into the handle's SoA, then build the work
+// list.  d_flags must be prepared by the caller ([1], [2] zero; [0] zero for a new batch).
+template <typename SRC>
+static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool reduce_time, hipStream_t s) {
+    const int ntiles = h->ntr * h->ntc, T = h->n_time_bin;
+    if (h->cap_alt < h->cap) {  // staging SoA of the bucket pass
         CMAX_CHECK_HIP(hipStreamSynchronize(s));
         dev_free(&h->evp_alt);
         dev_free(&h->rx_alt);
@@ -1437,22 +1362,21 @@ static int resort_events(cmax_handle_s *h, hipStream_t s) {
         if (rc) return rc;
         h->cap_alt = h->cap;
     }
-    const int nkeys = T > 0 ? h->ntr * h->ntc * T : h->nkeys;  // <= h->nkeys: T <= 255 < 256 pixels per tile
-    CMAX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)(nkeys + 1) * sizeof(int), s));
-    CMAX_CHECK_HIP(hipMemsetAsync(h->cursor, 0, (size_t)nkeys * sizeof(int), s));
-    const int grid = stream_grid(n, 256);
-    hipLaunchKernelGGL(k_rekey_hist, dim3(grid), dim3(256), 0, s, n, h->tau64, T, h->ntc, h->evp, h->key_tmp, h->counts);
-    launch_scan(h, nkeys, s);
-    hipLaunchKernelGGL(k_rescatter, dim3(grid), dim3(256), 0, s, n, h->key_tmp, h->counts, h->cursor, h->evp, h->rx, h->ry, h->tau64,
-                       h->evp_alt, h->rx_alt, h->ry_alt, h->tau64_alt);
+    CMAX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)(ntiles + 1) * sizeof(int), s));
+    CMAX_CHECK_HIP(hipMemsetAsync(h->cursor, 0, (size_t)ntiles * sizeof(int), s));
+    const int grid = (int)div_up(n_in, (int64_t)kSortChunk);
+    const SortOut stage = {h->evp_alt, h->rx_alt, h->ry_alt, h->tau64_alt};
+    const SortOut fin = {h->evp, h->rx, h->ry, h->tau64};
+    unsigned long long *keys = reduce_time ? reinterpret_cast<unsigned long long *>(h->d_tmm) : nullptr;
+    if (keys) CMAX_CHECK_HIP(hipMemsetAsync(keys, 0, 2 * sizeof(unsigned long long), s));  // "empty" for both atomicMax reductions
+    hipLaunchKernelGGL((k_bucket_hist<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, h->counts, h->d_flags, keys);
+    launch_scan(h, ntiles, s);
+    hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, stage);
+    hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->cursor, keys);  // cursor: free again, receives the active pixels per tile
     CMAX_CHECK_LAUNCH();
-    std::swap(h->evp, h->evp_alt);
-    std::swap(h->rx, h->rx_alt);
-    std::swap(h->ry, h->ry_alt);
-    std::swap(h->tau64, h->tau64_alt);
-    int rc_pad = pad_event_tail(h, s);
-    if (rc_pad) return rc_pad;
-    return build_segments(h, T > 0 ? 1 : 256, s);
+    BatchReadback rb;
+    rb.n_in = n_in;
+    return build_segments(h, T > 0 ? 1 : 256, s, &rb);
 }
 
 void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out) {
@@ -1547,7 +1471,6 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->rx);
     dev_free(&h->ry);
     dev_free(&h->tau64);
-    dev_free(&h->key_tmp);
     dev_free(&h->evp_alt);
     dev_free(&h->rx_alt);
     dev_free(&h->ry_alt);
@@ -1575,31 +1498,27 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         dev_free(&h->rx);
         dev_free(&h->ry);
         dev_free(&h->tau64);
-        dev_free(&h->key_tmp);
         int rc = dev_alloc(h, &h->evp, n + 2);  // +2: the vector loads may touch one event past the end
         if (!rc) rc = dev_alloc(h, &h->rx, n);
         if (!rc) rc = dev_alloc(h, &h->ry, n);
         if (!rc) rc = dev_alloc(h, &h->tau64, n);
-        if (!rc) rc = dev_alloc(h, &h->key_tmp, n);
         if (rc) return rc;
         h->cap = n;
-        dev_free(&h->evp_alt);  // re-allocated by the next re-sort
+        dev_free(&h->evp_alt);  // the staging SoA follows (sort_events)
         dev_free(&h->rx_alt);
         dev_free(&h->ry_alt);
         dev_free(&h->tau64_alt);
         h->cap_alt = 0;
     }
-    // global time extremes
+    // global time extremes: given (a time slice of a larger batch), or reduced by the first sort kernel
     if (have_tminmax) {
         CMAX_REQUIRE(tmax >= tmin, "set_events: tmax < tmin");
         hipLaunchKernelGGL(k_tmm_set, dim3(1), dim3(1), 0, s, h->d_tmm, tmin, tmax);
-    } else {
-        int rc = cmax_tminmax(events, dtype, n, h->d_tmm, stream);  // leaf reduction (cmax_leaf.hip)
-        if (rc) return rc;
+        CMAX_CHECK_LAUNCH();
+    } else if (n == 0) {
+        hipLaunchKernelGGL(k_tmm_set, dim3(1), dim3(1), 0, s, h->d_tmm, (double)INFINITY, -(double)INFINITY);
+        CMAX_CHECK_LAUNCH();
     }
-    CMAX_CHECK_LAUNCH();
-    CMAX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)(h->nkeys + 1) * sizeof(int), s));
-    CMAX_CHECK_HIP(hipMemsetAsync(h->cursor, 0, (size_t)h->nkeys * sizeof(int), s));
     CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
     h->n_time_bin = n_time_bin;
     if (n == 0) {
@@ -1607,28 +1526,10 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         h->nseg = 0;
         return 0;
     }
-    const int grid = stream_grid(n, 256);
-    if (dtype == CMAX_F32) hipLaunchKernelGGL(k_pack_hist<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->H, h->W, h->ntc, h->key_tmp, h->counts, h->d_flags);
-    else hipLaunchKernelGGL(k_pack_hist<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->H, h->W, h->ntc, h->key_tmp, h->counts, h->d_flags);
-    launch_scan(h, h->nkeys, s, h->d_flags + 2);  // also counts the source pixels that hold events
-    if (dtype == CMAX_F32) hipLaunchKernelGGL(k_scatter<float>, dim3(grid), dim3(256), 0, s, (const float *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
-    else hipLaunchKernelGGL(k_scatter<double>, dim3(grid), dim3(256), 0, s, (const double *)events, n, h->key_tmp, h->counts, h->cursor, h->d_tmm, n_time_bin, h->evp, h->rx, h->ry, h->tau64);
-    CMAX_CHECK_LAUNCH();
-    // once per batch: how many events survived and whether any source coordinate is fractional
-    int flags[4] = {0, 0, 0, 0};
-    double tmm_host[2] = {0.0, 0.0};
-    CMAX_CHECK_HIP(hipMemcpyAsync(tmm_host, h->d_tmm, sizeof(tmm_host), hipMemcpyDeviceToHost, s));
-    CMAX_CHECK_HIP(hipMemcpyAsync(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
-    CMAX_CHECK_HIP(hipStreamSynchronize(s));
-    h->has_frac = flags[0] != 0;
-    h->n = n - flags[1];
-    h->long_runs = flags[2] > 0 && h->n >= (int64_t)8 * flags[2];
-    h->tmin_host = tmm_host[0];
-    h->tmax_host = tmm_host[1];
-    int rc_pad = pad_event_tail(h, s);
-    if (rc_pad) return rc_pad;
-    if (n_time_bin > 0) return resort_events(h, s);  // (tile, bin) order + work list
-    return build_segments(h, 256, s);
+    // pack + order (tile-major; by pixel or by time bin inside a tile) + work list; one host synchronisation
+    const int keyed = have_tminmax ? 0 : 1;
+    if (dtype == CMAX_F32) return sort_events(h, RawSource<float>{(const float *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, s);
+    return sort_events(h, RawSource<double>{(const double *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, s);
 }
 
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
@@ -1638,7 +1539,10 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     h->n_time_bin = n_time_bin;
     ++h->generation;
     if (h->n == 0) return 0;
-    return resort_events(h, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    // re-order the packed events in place (through the staging SoA); [0] "fractional sources" stays what it was
+    CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(int), s));
+    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64}, h->n, false, s);
 }
 
 int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac, int normalize_t,
