@@ -338,3 +338,73 @@ def test_non_finite_inputs_do_not_poison_the_handle(model):
     h2.set_events(ev, time_bin=tb)
     loss, g = run(good, h2)
     assert abs(loss - ref["loss"]) <= 1e-4 * abs(ref["loss"])
+
+
+# ---- exact Hessian-vector product of the fused objective: symmetry and agreement with a difference quotient ----------------
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CMAX_FUZZ_SEEDS", "18"))))
+def test_random_fused_hvp_is_symmetric(seed):
+    rng = np.random.default_rng(7000 + seed)
+    H, W = int(rng.integers(12, 70)), int(rng.integers(12, 90))
+    pad = int(rng.choice([0, 0, 2]))
+    n = int(rng.choice([60, 2000, 30000]))
+    model = MODELS[seed % 3]
+    cost = COSTS[(seed // 3) % len(COSTS)]
+    sigma = int(rng.integers(0, 2))
+    vel = rng.uniform(-6, 6, 2)
+    ev = E.utils.generate_structured_events(n, H, W, tuple(vel), n_dots=max(3, n // 60), seed=seed)
+    T = int(rng.choice([2, 5])) if model == "dense-flow-voxel" else 0
+    if model == "2d-translation":
+        motion = vel * 0.9
+    else:
+        f0 = -(E.utils.generate_smooth_flow((H, W), 2.0, grid=3, seed=seed) + vel[:, None, None] * 0.9)
+        motion = f0 if model == "dense-flow" else np.stack([f0 * (1 + 0.03 * k) for k in range(T)])
+    h = E.CMaxHandle((H, W), pad).set_events(ev, time_bin=T)
+    obj = E.ContrastObjective(h, model, cost=cost, sigma=sigma)
+    assert obj.has_exact_hvp
+    m = torch.as_tensor(np.ascontiguousarray(motion), dtype=torch.float64, device="cuda")
+    if model == "2d-translation":
+        u, v = torch.tensor([1.0, 0.3], dtype=torch.float64, device="cuda"), torch.tensor([-0.4, 1.0], dtype=torch.float64, device="cuda")
+    else:  # smooth directions (what an optimiser on a patch grid produces)
+        u = torch.as_tensor(np.broadcast_to(E.utils.generate_smooth_flow((H, W), 1.0, grid=3, seed=seed + 50), m.shape).copy(), device="cuda")
+        v = torch.as_tensor(np.broadcast_to(E.utils.generate_smooth_flow((H, W), 1.0, grid=4, seed=seed + 90), m.shape).copy(), device="cuda")
+    hu, hv = obj.hvp(m, u).double(), obj.hvp(m, v).double()
+    info = (H, W, pad, n, model, cost, sigma, T)
+    assert torch.isfinite(hu).all() and torch.isfinite(hv).all(), info
+    a, b = float((v * hu).sum()), float((u * hv).sum())
+    assert abs(a - b) <= 2e-3 * max(abs(a), abs(b)) + 2e-4 * min(float((v * hu).abs().sum()), float((u * hv).abs().sum())), (info, a, b)
+
+
+# ---- time slices: votes of disjoint slices add up to the whole batch, the gradient parts add up to the whole gradient ----------
+@pytest.mark.parametrize("seed", range(9))
+def test_random_time_slices_sum_to_the_whole(seed):
+    rng = np.random.default_rng(8000 + seed)
+    H, W = int(rng.integers(20, 80)), int(rng.integers(20, 100))
+    n = int(rng.choice([500, 8000, 50000]))
+    model = MODELS[seed % 3]
+    cost = COSTS[(seed // 3 + seed) % len(COSTS)]
+    sigma = int(rng.integers(0, 2))
+    vel = rng.uniform(-6, 6, 2)
+    ev = E.utils.generate_structured_events(n, H, W, tuple(vel), n_dots=max(3, n // 60), seed=seed)
+    T = 4 if model == "dense-flow-voxel" else 0
+    if model == "2d-translation":
+        motion = vel
+    else:
+        f0 = -(E.utils.generate_smooth_flow((H, W), 2.0, grid=3, seed=seed) + vel[:, None, None])
+        motion = f0 if model == "dense-flow" else np.stack([f0] * T)
+    desc = E.make_descriptor(cost, model, sigma=sigma, time_bin=T)
+    m = torch.as_tensor(np.ascontiguousarray(motion), dtype=torch.float32, device="cuda")
+    whole = E.CMaxHandle((H, W)).set_events(ev, time_bin=T)
+    res_w, grad_w = whole.evaluate(desc, m, True)
+    k = int(rng.integers(2, 6))
+    cuts = np.sort(rng.choice(np.arange(1, n), size=k - 1, replace=False))
+    bounds = [0] + list(cuts) + [n]
+    tmin, tmax = float(ev[:, 2].min()), float(ev[:, 2].max())
+    handles = [E.CMaxHandle((H, W)).set_events(ev[a:b], tmin, tmax, time_bin=T) for a, b in zip(bounds[:-1], bounds[1:])]
+    images = sum(hd.objective_vote(desc, m) for hd in handles)
+    parts = [hd.objective_finish(desc, m, images, True) for hd in handles]
+    grad = sum(p[1].double() for p in parts)
+    info = (H, W, n, model, cost, sigma, k)
+    for res, _ in parts:
+        assert abs(res[0].item() - res_w[0].item()) <= 1e-5 * abs(res_w[0].item()), (info, res[0].item(), res_w[0].item())
+    gmax = grad_w.abs().max().item()
+    assert (grad - grad_w.double()).abs().max().item() <= 2e-4 * gmax, (info, (grad - grad_w.double()).abs().max().item(), gmax)
