@@ -15,7 +15,9 @@ One JSON line on stdout (rank 0).  Extra objects:
                 measured with HIP events on the launch stream in an instrumented pass of the same K
                 steps (cmax_set_profiling); peak = 8.0 TB/s HBM (MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (oracle/cmax_oracle.c, scalar C, 1 core) timed on this host on the
-                same workload -- a reported baseline, not the target
+                same workload -- a reported baseline, not the target; cpu_baseline_torch: the same evaluation
+                written the way the reference is (torch tensor ops + autograd, oracle/torch_cpu.py) on the
+                host's cores
 """
 import argparse
 import json
@@ -102,6 +104,30 @@ def cpu_baseline(cfg, ev, motion, budget_s=12.0):
     return {"value": ev.shape[0] * reps / el, "unit": "events/s", "cores": 1, "kind": "port",
             "sample": f"{reps} full evaluations (value+gradient) of the same {ev.shape[0]}-event workload, "
                       f"oracle/cmax_oracle.c fp64 scalar C, {el:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_torch(cfg, ev, motion, budget_s=8.0):
+    """The reference's own kind of CPU code (tensor ops + torch.autograd, oracle/torch_cpu.py) on this host's cores."""
+    import torch
+
+    from oracle import torch_cpu
+
+    if cfg["sigma"] > 0 or cfg["model"] not in ("2d-translation", "dense-flow") or cfg["cost"] not in ("image_variance", "gradient_magnitude"):
+        return None
+    size = (cfg["H"], cfg["W"])
+    torch_cpu.value_and_grad(ev[:1000], motion, cfg["model"], size, cfg["cost"])
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        torch_cpu.value_and_grad(ev, motion, cfg["model"], size, cfg["cost"])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 200:
+            break
+    return {"value": ev.shape[0] * reps / el, "unit": "events/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} full evaluations (value + autograd gradient) of the same {ev.shape[0]}-event workload, torch-CPU fp64 "
+                      f"restatement of the reference's tensor path (oracle/torch_cpu.py), {el:.1f} s",
             "host_cpus": os.cpu_count()}
 
 
@@ -252,6 +278,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ev, motion)
+            tc = cpu_baseline_torch(cfg, ev, motion)
+            if tc is not None:
+                out["cpu_baseline_torch"] = tc
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

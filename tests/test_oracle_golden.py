@@ -212,3 +212,21 @@ def test_patch_search_cost(golden, scale):
     np.testing.assert_allclose(loss, g[k + "__loss"], rtol=1e-10)
     # the un-warped image is candidate 0 px/s: loss exactly 1 (column 1 of the fixture's candidates)
     np.testing.assert_allclose(loss[:, 1], 1.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("model", ["2d-translation", "dense-flow"])
+@pytest.mark.parametrize("cost", ["image_variance", "gradient_magnitude"])
+def test_torch_cpu_restatement_matches_the_c_oracle(golden, model, cost):
+    """oracle/torch_cpu.py (the reference's kind of code: tensor ops + autograd; bench.py times it on the host cores)
+    against the C restatement on the fixture's inputs, and through it against the reference's values."""
+    from oracle import torch_cpu
+
+    g = golden("objective")
+    size = tuple(int(v) for v in g["image_size"])
+    motion = g["theta"] if model == "2d-translation" else g["flow_smooth"]
+    ref = orc.objective(g["events"], motion, model, size, cost=cost, sigma=0)
+    loss, grad = torch_cpu.value_and_grad(g["events"], motion, model, size, cost)
+    assert abs(loss - ref["loss"]) <= 1e-12 * abs(ref["loss"])
+    np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=1e-11 * np.abs(ref["grad"]).max())
+    tag = ("2dof" if model == "2d-translation" else "dense_smooth") + f"__{cost}__s0"
+    assert abs(loss - g[tag + "__loss"]) <= 1e-10 * abs(g[tag + "__loss"])
