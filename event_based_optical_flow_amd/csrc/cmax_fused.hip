@@ -1371,8 +1371,8 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
     if (keys) CMAX_CHECK_HIP(hipMemsetAsync(keys, 0, 2 * sizeof(unsigned long long), s));  // "empty" for both atomicMax reductions
     hipLaunchKernelGGL((k_bucket_hist<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, h->counts, h->d_flags, keys);
     launch_scan(h, ntiles, s);
-    hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, stage);
-    hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->cursor, keys);  // cursor: free again, receives the active pixels per tile
+    hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, h->d_flags, stage);
+    hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->cursor, h->d_flags, keys);  // cursor: free again, receives the active pixels per tile
     CMAX_CHECK_LAUNCH();
     BatchReadback rb;
     rb.n_in = n_in;
@@ -1542,7 +1542,7 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     // re-order the packed events in place (through the staging SoA); [0] "fractional sources" stays what it was
     CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(int), s));
-    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64}, h->n, false, s);
+    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, s);
 }
 
 int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac, int normalize_t,

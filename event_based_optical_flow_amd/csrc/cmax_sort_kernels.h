@@ -107,8 +107,9 @@ struct RawSource {
 // the handle's own packed SoA (re-binning)
 struct PackedSource {
     const uint2 *evp;
-    const float *rx, *ry;
+    const float *rx, *ry;  // written only for batches with fractional source coordinates (has_frac)
     const double *tau64;
+    int has_frac;
     __device__ __forceinline__ bool reduces_time() const { return false; }
     __device__ __forceinline__ double time(int64_t) const { return 0.0; }
     __device__ __forceinline__ SortItem pixel(int64_t i) const {
@@ -121,8 +122,8 @@ struct PackedSource {
     }
     __device__ __forceinline__ SortItem full(int64_t i) const {
         SortItem it = pixel(i);
-        it.rx = rx[i];
-        it.ry = ry[i];
+        it.rx = has_frac ? rx[i] : 0.f;
+        it.ry = has_frac ? ry[i] : 0.f;
         it.tn = tau64[i];
         return it;
     }
@@ -207,10 +208,14 @@ k_bucket_hist(SRC src, int64_t n, int ntc, int ntiles, int *__restrict__ tile_co
 // S3.  tile_off: exclusive scan of the tile counts; tile_cursor: zero on entry.
 template <typename SRC>
 __global__ void __launch_bounds__(kSortThreads)
-k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__restrict__ tile_off, int *__restrict__ tile_cursor, SortOut out) {
+k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__restrict__ tile_off, int *__restrict__ tile_cursor,
+                 const int *__restrict__ flags, SortOut out) {
     __shared__ int s_hist[kSortLdsTiles];  // count, then running slot
     __shared__ int s_base[kSortLdsTiles];
     const bool lds = ntiles <= kSortLdsTiles;
+    // flags[0] (complete: S1 wrote it): any fractional source coordinate.  Sensor batches have none; the rx / ry arrays
+    // are then never read by anyone, and two of the four scattered stores per event are saved here and in S4.
+    const bool frac = flags[0] != 0;
     const int64_t base = (int64_t)blockIdx.x * kSortChunk;
     if (lds) {
         for (int t = threadIdx.x; t < ntiles; t += kSortThreads) s_hist[t] = 0;
@@ -244,8 +249,10 @@ k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__re
         const int pos = lds ? s_base[tile[u]] + atomicAdd(&s_hist[tile[u]], 1) : tile_off[tile[u]] + atomicAdd(&tile_cursor[tile[u]], 1);
         const uint32_t bin = T > 0 ? (uint32_t)sort_voxel_bin(it.tn, T) : 0u;
         out.evp[pos] = make_uint2((uint32_t)it.ix | ((uint32_t)it.iy << 12) | (bin << 24), __float_as_uint((float)it.tn));
-        out.rx[pos] = it.rx;
-        out.ry[pos] = it.ry;
+        if (frac) {
+            out.rx[pos] = it.rx;
+            out.ry[pos] = it.ry;
+        }
         out.tau64[pos] = it.tn;
     }
 }
@@ -255,7 +262,8 @@ k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__re
 // doubles by the first workgroup (nothing in this launch reads them).
 __global__ void __launch_bounds__(kTileSortThreads)
 k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, SortOut out, int *__restrict__ group_start, int *__restrict__ active,
-            unsigned long long *__restrict__ tmm_keys) {
+            const int *__restrict__ flags, unsigned long long *__restrict__ tmm_keys) {
+    const bool frac = flags[0] != 0;
     __shared__ int s_cnt[256], s_cur[256];
     __shared__ int s_wave[256 / kWave], s_wave2[256 / kWave];
     const int tile = blockIdx.x;
@@ -312,18 +320,30 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
     for (int i0 = b + 2 * t; i0 < e; i0 += 2 * kTileSortThreads) {
         const bool two = i0 + 1 < e;
         const uint2 ea = in.evp[i0], eb = two ? in.evp[i0 + 1] : make_uint2(0u, 0u);
-        const float rxa = in.rx[i0], rya = in.ry[i0], rxb = two ? in.rx[i0 + 1] : 0.f, ryb = two ? in.ry[i0 + 1] : 0.f;
+        float rxa = 0.f, rya = 0.f, rxb = 0.f, ryb = 0.f;
+        if (frac) {
+            rxa = in.rx[i0];
+            rya = in.ry[i0];
+            if (two) {
+                rxb = in.rx[i0 + 1];
+                ryb = in.ry[i0 + 1];
+            }
+        }
         const double ta = in.tau64[i0], tb = two ? in.tau64[i0 + 1] : 0.0;
         const int pa = b + atomicAdd(&s_cur[sub_key(ea.x)], 1);
         out.evp[pa] = ea;
-        out.rx[pa] = rxa;
-        out.ry[pa] = rya;
+        if (frac) {
+            out.rx[pa] = rxa;
+            out.ry[pa] = rya;
+        }
         out.tau64[pa] = ta;
         if (two) {
             const int pb = b + atomicAdd(&s_cur[sub_key(eb.x)], 1);
             out.evp[pb] = eb;
-            out.rx[pb] = rxb;
-            out.ry[pb] = ryb;
+            if (frac) {
+                out.rx[pb] = rxb;
+                out.ry[pb] = ryb;
+            }
             out.tau64[pb] = tb;
         }
     }
