@@ -33,6 +33,7 @@
 // fp32 per event with the integer source pixel split from the fp32 displacement (keeps the
 // bilinear fractions accurate to ulp(displacement) instead of ulp(coordinate)); fp64 reductions.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "cmax_common.h"
@@ -143,6 +144,13 @@ struct cmax_handle_s {
     double tmin_host = 0.0, tmax_host = 0.0;  // batch extremes (copied once per batch)
     float *hvp_img = nullptr;                 // [6 kinds][4 reference times][Hp, Wp] scratch of cmax_objective_hvp (allocated on first use)
     double *d_stat_tan = nullptr;             // [4][kStatStride] tangent statistics
+    // pinned host staging of the per-batch read-back (group starts, active pixels per tile, flags, time extremes) and
+    // of the work list: copies to / from pageable memory are staged by the runtime and cost a synchronisation each
+    int *hp_read = nullptr;
+    int64_t hp_read_cap = 0;
+    int4 *hp_segs = nullptr;
+    int64_t hp_segs_cap = 0;
+    hipEvent_t segs_copied = nullptr;  // the last upload of hp_segs has left the host buffer
     float2 *search_range = nullptr;           // [search_cap] (tau_min, tau_max) per patch of cmax_patch_search
     int search_cap = 0;
     int64_t bytes = 0;
@@ -291,6 +299,34 @@ __global__ void __launch_bounds__(256) k_scan_apply(int *__restrict__ counts, in
         if (base + u < m) counts[base + u] = run;
         run += c[u];
     }
+}
+
+// m <= 4096: the whole scan in one workgroup (thread q owns counts[4q .. 4q+3]) instead of three launches
+__global__ void __launch_bounds__(1024) k_scan_small(int *__restrict__ counts, int m) {
+    __shared__ int s_w[1024 / kWave];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    int c[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = 4 * t + j < m ? counts[4 * t + j] : 0;
+        sum += c[j];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += v;
+    }
+    if (lane == kWave - 1) s_w[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (4 * t + j < m) counts[4 * t + j] = run;
+        run += c[j];
+    }
+    if (t == 1023) counts[m] = run;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1040,6 +1076,10 @@ k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *_
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of h->counts[0..m) in place, counts[m] = total
 static void launch_scan(cmax_handle_s *h, int m, hipStream_t s, int *nonzero = nullptr) {
+    if (m <= 4096 && !nonzero) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, h->counts, m);
+        return;
+    }
     const int nchunk = div_up(m, kScanChunk);
     hipLaunchKernelGGL(k_scan_sums, dim3(nchunk), dim3(256), 0, s, h->counts, m, h->scan_tmp, nonzero);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, h->scan_tmp, nchunk, h->counts + m);
@@ -1262,30 +1302,51 @@ struct BatchReadback {
 //   * smaller batches are latency-bound: small groups are merged while they fit, a group with more than
 //     kSegMax events is split into EQUAL parts -- group-aligned windows are tighter and no workgroup is left
 //     with a small remainder (cfg2: 2040 + 806 per tile -> 2 x 1423).
+template <typename T>
+static int pinned_reserve(T **p, int64_t *cap, int64_t count) {
+    if (count <= *cap) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const int64_t want = count + count / 2 + 64;
+    if (hipHostMalloc((void **)p, (size_t)want * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc(%lld bytes) failed", (long long)(want * sizeof(T)));
+        return CMAX_ENOMEM;
+    }
+    *cap = want;
+    return 0;
+}
+
 static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchReadback *rb = nullptr) {
     const int T = stride == 1 ? h->n_time_bin : 1;  // groups per tile
     const int ngroups = h->ntr * h->ntc * T;
-    std::vector<int> group_start((size_t)ngroups + 1);
-    CMAX_CHECK_HIP(hipMemcpyAsync(group_start.data(), h->d_tile_start, group_start.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-    std::vector<int> tile_active;
+    const int ntiles = h->ntr * h->ntc;
+    const bool want_active = rb && h->n_time_bin == 0;
+    // layout of the pinned read-back: [ngroups + 1] group starts | [ntiles] active pixels | [4] flags | [2 doubles] extremes
+    const int64_t off_active = ngroups + 1, off_flags = off_active + (want_active ? ntiles : 0);
+    const int64_t off_tmm = (off_flags + 4 + 1) & ~(int64_t)1;  // 8-byte aligned
+    int rc = pinned_reserve(&h->hp_read, &h->hp_read_cap, off_tmm + 4);
+    if (rc) return rc;
+    const int *group_start = h->hp_read;
+    CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read, h->d_tile_start, (size_t)(ngroups + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
     if (rb) {  // what the host needs to know about the batch rides on the same synchronisation
-        if (T == 1 && h->n_time_bin == 0) {
-            tile_active.resize((size_t)h->ntr * h->ntc);
-            CMAX_CHECK_HIP(hipMemcpyAsync(tile_active.data(), h->cursor, tile_active.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-        }
-        CMAX_CHECK_HIP(hipMemcpyAsync(rb->flags, h->d_flags, sizeof(rb->flags), hipMemcpyDeviceToHost, s));
-        CMAX_CHECK_HIP(hipMemcpyAsync(rb->tmm, h->d_tmm, sizeof(rb->tmm), hipMemcpyDeviceToHost, s));
+        if (want_active) CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read + off_active, h->cursor, (size_t)ntiles * sizeof(int), hipMemcpyDeviceToHost, s));
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read + off_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read + off_tmm, h->d_tmm, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
     if (rb) {
+        for (int k = 0; k < 4; ++k) rb->flags[k] = h->hp_read[off_flags + k];
+        std::memcpy(rb->tmm, h->hp_read + off_tmm, 2 * sizeof(double));
         h->has_frac = rb->flags[0] != 0;
         h->n = rb->n_in - rb->flags[1];
         int64_t active = 0;  // source pixels that hold events (un-binned order)
-        for (int a : tile_active) active += a;
+        if (want_active)
+            for (int k = 0; k < ntiles; ++k) active += h->hp_read[off_active + k];
         h->long_runs = active > 0 && h->n >= 8 * active;
         h->tmin_host = rb->tmm[0];
         h->tmax_host = rb->tmm[1];
-        int rc = pad_event_tail(h, s);
+        rc = pad_event_tail(h, s);
         if (rc) return rc;
     }
     const int max_groups = kAccCells / 256;
@@ -1338,8 +1399,14 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         h->seg_cap = h->nseg;
     }
     if (h->nseg > 0) {
-        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        CMAX_CHECK_HIP(hipStreamSynchronize(s));  // `segs` is a host temporary
+        // upload from pinned memory, no wait: the buffer is only rewritten after the event below has passed
+        if (h->segs_copied) CMAX_CHECK_HIP(hipEventSynchronize(h->segs_copied));
+        else CMAX_CHECK_HIP(hipEventCreateWithFlags(&h->segs_copied, hipEventDisableTiming));
+        rc = pinned_reserve(&h->hp_segs, &h->hp_segs_cap, h->nseg);
+        if (rc) return rc;
+        std::memcpy(h->hp_segs, segs.data(), segs.size() * sizeof(int4));
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, h->hp_segs, segs.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        CMAX_CHECK_HIP(hipEventRecord(h->segs_copied, s));
     }
     return 0;
 }
@@ -1459,6 +1526,9 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->hvp_img);
     dev_free(&h->d_stat_tan);
     dev_free(&h->search_range);
+    if (h->hp_read) (void)hipHostFree(h->hp_read);
+    if (h->hp_segs) (void)hipHostFree(h->hp_segs);
+    if (h->segs_copied) (void)hipEventDestroy(h->segs_copied);
     dev_free(&h->d_gpart);
     dev_free(&h->counts);
     dev_free(&h->cursor);
