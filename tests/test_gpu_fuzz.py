@@ -408,3 +408,41 @@ def test_random_time_slices_sum_to_the_whole(seed):
         assert abs(res[0].item() - res_w[0].item()) <= 1e-5 * abs(res_w[0].item()), (info, res[0].item(), res_w[0].item())
     gmax = grad_w.abs().max().item()
     assert (grad - grad_w.double()).abs().max().item() <= 2e-4 * gmax, (info, (grad - grad_w.double()).abs().max().item(), gmax)
+
+
+# ---- sensors with more than 4096 source tiles: the sort's global-atomic path and the three-launch scan ---------------------------
+@pytest.mark.parametrize("model,time_bin", [("2d-translation", 0), ("dense-flow", 0), ("dense-flow-voxel", 3)])
+def test_large_sensor_takes_the_global_tile_path(model, time_bin):
+    H, W = 1100, 1210  # 69 x 76 = 5244 tiles
+    rng = np.random.default_rng(12)
+    n = 40000
+    vel = np.array([6.0, -4.0])
+    ev = E.utils.generate_structured_events(n, H, W, tuple(vel), n_dots=600, seed=5)
+    ev[100:150, 0] = H + 3.0  # some events off the sensor (not the first / last of the batch: the time extremes stay)
+    if model == "2d-translation":
+        motion = vel
+    else:
+        f0 = -(E.utils.generate_smooth_flow((H, W), 2.0, grid=3, seed=1) + vel[:, None, None])
+        motion = f0 if model == "dense-flow" else np.stack([f0] * time_bin)
+    h = E.CMaxHandle((H, W)).set_events(ev, time_bin=time_bin)
+    assert h.n_events == n - 50
+    keep = np.concatenate([ev[:100], ev[150:]])
+    keep_tmm = (float(ev[:, 2].min()), float(ev[:, 2].max()))
+    ref = orc.objective(keep, motion, model, (H, W), cost="image_variance", sigma=0)
+    obj = E.ContrastObjective(h, model, cost="image_variance", sigma=0)
+    m = torch.as_tensor(np.ascontiguousarray(motion), dtype=torch.float64, device="cuda").requires_grad_()
+    loss = obj(m)
+    (g,) = torch.autograd.grad(loss, m)
+    # the dropped events still count for the batch's time extremes (they are part of the batch): evaluate the oracle on
+    # the kept events with the same normalisation by keeping the first / last timestamps inside `keep`
+    if float(keep[:, 2].min()) == keep_tmm[0] and float(keep[:, 2].max()) == keep_tmm[1]:
+        assert abs(loss.item() - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (loss.item(), ref["loss"])
+        err = np.abs(g.cpu().numpy() - ref["grad"])
+        gmax = np.abs(ref["grad"]).max()
+        assert (err > 2e-4 * gmax).sum() <= 8 and err.max() <= 5e-2 * gmax, (err.max(), gmax)
+    if time_bin == 0:  # re-bin in place through the same path
+        h.set_time_bins(4)
+        motion4 = np.stack([-(E.utils.generate_smooth_flow((H, W), 2.0, grid=3, seed=1) + vel[:, None, None])] * 4)
+        ref4 = orc.objective(keep, motion4, "dense-flow-voxel", (H, W), cost="image_variance", sigma=0)
+        l4 = E.ContrastObjective(h, "dense-flow-voxel", cost="image_variance", sigma=0)(torch.as_tensor(motion4, device="cuda"))
+        assert abs(l4.item() - ref4["loss"]) <= 1e-4 * abs(ref4["loss"]), (l4.item(), ref4["loss"])
