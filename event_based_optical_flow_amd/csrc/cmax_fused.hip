@@ -380,8 +380,12 @@ __device__ __forceinline__ float time_scale(const WarpParams &wp) {
 // contiguous range [x * per, (x+1) * per) keeps neighbouring tiles (shared halo rows of the IWE / G
 // windows, neighbouring flow pixels) in one XCD's L2.  Placement only affects speed.
 __device__ __forceinline__ int segment_of_block(int nseg) {
+#ifdef CMAX_NO_XCD_MAP
+    return (int)blockIdx.x;
+#else
     const int per = (nseg + 7) >> 3;
     return (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+#endif
 }
 
 struct Window {
@@ -1349,7 +1353,11 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         rc = pad_event_tail(h, s);
         if (rc) return rc;
     }
-    const int max_groups = kAccCells / 256;
+    // un-binned handles: a segment spans <= 3 source tiles.  Sparse tiles used to be merged up to 12 wide; the LDS
+    // window of such a segment (16 * span + displacement range wide) overflowed its 4096 words as soon as the motion
+    // was a few pixels, and the clipped path (bounds tests, global atomics for the overflow) made those few workgroups
+    // the tail of the launch: 1M events whose lower tile rows are sparse, K1 7.5 -> 6.9 us, K3 10.4 -> 7.3 us.
+    const int max_groups = T == 1 ? 3 : kAccCells / 256;
     const bool free_cut = h->n > (int64_t)1024 * kSegMax;
     // batches far below one full segment per CU (the solver's 30k-event slices): a workgroup walks its events
     // 8 (4) per thread, so 2040-event segments leave 15 workgroups with long serial work on a 256-CU chip.
