@@ -44,7 +44,6 @@
 namespace cmax {
 
 constexpr int kTile = 16;  // source-pixel tile edge of the counting sort
-constexpr uint32_t kDropped = 0xFFFFFFFFu;
 constexpr int kSegMax = 2040;                 // events per segment (+1 for the even-aligned start still fits 2048);
                                               // |sum of votes| <= 2040 * 2^20 < 2^31
 constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit words (32 KiB)
