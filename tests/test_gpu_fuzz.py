@@ -61,16 +61,24 @@ def test_random_configuration_against_oracle(seed):
     # floor(x' + 1e-6) is discontinuous: an event whose warped coordinate lies within fp32 rounding of a cell border
     # votes into the neighbouring cell in fp32 (the reference in fp32 would too).  Such draws are compared at the
     # size of one event's contribution instead of the gate.
-    tol = 1e-4
+    tol, n_border = 1e-4, 0
     for direction in ("first", "middle", "last"):
         w, _ = orc.warp_event(c["ev"], c["motion"], c["model"], direction, size)
         frac = np.mod(w[:, :2] + 1e-6, 1.0)
-        if np.isfinite(frac).all() and np.minimum(frac, 1.0 - frac).min() < 3e-5:
-            tol = 2e-2
+        if np.isfinite(frac).all():
+            n_border += int((np.minimum(frac, 1.0 - frac) < 3e-5).sum())
+    if n_border:
+        tol = 2e-2
     assert abs(loss.item() - ref["loss"]) <= tol * max(abs(ref["loss"]), 1e-12), (info, loss.item(), ref["loss"])
     gmax = np.abs(ref["grad"]).max()
     if gmax > 0:
-        assert np.abs(g - ref["grad"]).max() <= tol * gmax, (info, tol, np.abs(g - ref["grad"]).max(), gmax)
+        err = np.abs(g - ref["grad"])
+        if n_border and c["model"] != "2d-translation":
+            # per-pixel gradients: an event ON a cell border leaves the image unchanged but takes its derivative from the
+            # neighbouring cell -- its own flow-gradient pixel (x, y channel, per reference time) differs by one event's term
+            assert (err > 1e-4 * gmax).sum() <= 6 * n_border and err.max() <= gmax, (info, n_border, err.max(), gmax)
+        else:
+            assert err.max() <= tol * gmax, (info, tol, err.max(), gmax)
     else:
         assert np.abs(g).max() == 0, info
 
@@ -113,6 +121,11 @@ def test_random_solver_objective_against_oracle(seed):
                              t0_flow_location=c["t0"])
     info = {k: c[k] for k in ("H", "W", "pis", "psize", "shift", "time_aware", "cost", "sigma", "T", "scheme", "t0")}
     assert obj.has_native_plan, info
+    if not np.isfinite(ref_loss):  # degenerate draw (an IWE without contrast under a normalised cost): both sides must say so
+        w = TorchWrapper(obj, precision="float64")
+        w.get_input(c["x"])
+        assert not np.isfinite(w.get_value_and_grad(c["x"])[0]), info
+        return
     gmax = np.abs(ref_grad).max()
     for path in ("native", "native again", "autograd"):
         w = TorchWrapper(obj, precision="float64")
