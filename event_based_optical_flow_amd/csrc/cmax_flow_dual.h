@@ -97,103 +97,137 @@ __global__ void __launch_bounds__(256) k_flow_step_dual(DualJobs<T> jobs, int H,
     jobs.ddst[y][hw + p] = nv.d * s;
 }
 
-// adjoint step on dual numbers, scatter form like flow_step_adj_pixel: F -> (V_i, dV_i), upstream (lambda, dlambda)
+// Tile geometry of the atomic-free adjoint steps (k_flow_step_adj_tiled in cmax_flow.hip and the dual version below):
+// one workgroup owns a 16 x 32 tile of the destination, evaluates the scatter of the tile's pixels and of the ring
+// around it, keeps what lands inside the tile in LDS and adds it to the destination with plain read-modify-writes.
+constexpr int kAdjTileH = 16, kAdjTileW = 32, kAdjThreads = 1024;
+
+// adjoint step on dual numbers, scatter form like flow_step_adj_core: F -> (V_i, dV_i), upstream (lambda, dlambda).
+// The jobs of a launch (both time directions) run one after the other in the workgroup.
 template <typename T, int SCHEME>
-__global__ void __launch_bounds__(256) k_flow_step_adj_dual(DualJobs<T> jobs, int H, int W, T tau) {
+__global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_dual(DualJobs<T> jobs, int n_jobs, int H, int W, T tau) {
     using N = Dual<T>;
-    const int y = blockIdx.y;
-    const T *F = jobs.src[y], *dF = jobs.dsrc[y], *gout = jobs.gout[y], *dgout = jobs.dgout[y];
-    T *gF = jobs.dst[y], *dgF = jobs.ddst[y];
-    const T s = jobs.s[y];
+    __shared__ T acc[4][kAdjTileH * kAdjTileW];  // lambda u, lambda v, dlambda u, dlambda v
     const int64_t hw = (int64_t)H * W;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= hw) return;
-    const int i = (int)(p / W), j = (int)(p % W);
-    auto U = [&](int r, int c) { return N(s * F[(int64_t)r * W + c], s * dF[(int64_t)r * W + c]); };
-    auto V = [&](int r, int c) { return N(s * F[hw + (int64_t)r * W + c], s * dF[hw + (int64_t)r * W + c]); };
-    auto GU = [&](int r, int c, N val) {
-        atomic_add(&gF[(int64_t)r * W + c], val.v);
-        atomic_add(&dgF[(int64_t)r * W + c], val.d);
-    };
-    auto GV = [&](int r, int c, N val) {
-        atomic_add(&gF[hw + (int64_t)r * W + c], val.v);
-        atomic_add(&dgF[hw + (int64_t)r * W + c], val.d);
-    };
-    const N u = U(i, j), v = V(i, j), zero;
-    const N gnu(gout[p], dgout[p]), gnv(gout[hw + p], dgout[hw + p]);
-    const T mt = -tau;
-    if (SCHEME == CMAX_SCHEME_BURGERS) {
-        const int ip = i + 1 < H ? i + 1 : H - 1, im = i > 0 ? i - 1 : 0;
-        const int jp = j + 1 < W ? j + 1 : W - 1, jm = j > 0 ? j - 1 : 0;
-        const N uf = U(ip, j), ub = U(im, j), vf = V(i, jp), vb = V(i, jm);
-        const N u_dy_back = j > 0 ? u - U(i, j - 1) : zero, u_dy_forw = j + 1 < W ? U(i, j + 1) - u : zero;
-        const N v_dx_back = i > 0 ? v - V(i - 1, j) : zero, v_dx_forw = i + 1 < H ? V(i + 1, j) - v : zero;
-        const N one((T)1, (T)0);
-        // channel u
-        N self_u = gnu * (one - d_abs(u) * tau);  // d(u|u|/2)/du = |u|
-        GU(im, j, gnu * (-d_max0(ub)) * mt);
-        GU(ip, j, gnu * d_min0(uf) * mt);
-        N self_v = gnu * (u_dy_back * d_dmax0(v) + u_dy_forw * d_dmin0(v)) * mt;
-        const N mvp = d_max0(v), mvn = d_min0(v);
-        if (j > 0) {
-            self_u = self_u + gnu * mvp * mt;
-            GU(i, j - 1, -(gnu * mvp * mt));
-        }
-        if (j + 1 < W) {
-            GU(i, j + 1, gnu * mvn * mt);
-            self_u = self_u - gnu * mvn * mt;
-        }
-        // channel v
-        self_v = self_v + gnv * (one - d_abs(v) * tau);
-        GV(i, jm, gnv * (-d_max0(vb)) * mt);
-        GV(i, jp, gnv * d_min0(vf) * mt);
-        self_u = self_u + gnv * (v_dx_back * d_dmax0(u) + v_dx_forw * d_dmin0(u)) * mt;
-        const N mup = d_max0(u), mun = d_min0(u);
-        if (i > 0) {
-            self_v = self_v + gnv * mup * mt;
-            GV(i - 1, j, -(gnv * mup * mt));
-        }
-        if (i + 1 < H) {
-            GV(i + 1, j, gnv * mun * mt);
-            self_v = self_v - gnv * mun * mt;
-        }
-        GU(i, j, self_u);
-        GV(i, j, self_v);
-    } else {
-        const N mup = d_max0(u), mun = d_min0(u), mvp = d_max0(v), mvn = d_min0(v);
-        N self[2];
-        for (int c = 0; c < 2; ++c) {
-            const N g = c == 0 ? gnu : gnv;
-            auto Cc = [&](int r, int q) { return c == 0 ? U(r, q) : V(r, q); };
-            auto GC = [&](int r, int q, N val) {
-                if (c == 0) GU(r, q, val);
-                else GV(r, q, val);
+    const int tiles_w = (W + kAdjTileW - 1) / kAdjTileW;
+    const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
+    const int R0 = tr * kAdjTileH, C0 = tc * kAdjTileW;
+    constexpr int RH = kAdjTileH + 2, RW = kAdjTileW + 2;
+    for (int y = 0; y < n_jobs; ++y) {
+        const T *F = jobs.src[y], *dF = jobs.dsrc[y], *gout = jobs.gout[y], *dgout = jobs.dgout[y];
+        T *gF = jobs.dst[y], *dgF = jobs.ddst[y];
+        const T s = jobs.s[y];
+        for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjThreads) acc[0][q] = acc[1][q] = acc[2][q] = acc[3][q] = (T)0;
+        __syncthreads();
+        for (int q = threadIdx.x; q < RH * RW; q += kAdjThreads) {
+            const int a = q / RW, b = q - a * RW, i = R0 - 1 + a, j = C0 - 1 + b;
+            if ((unsigned)i >= (unsigned)H || (unsigned)j >= (unsigned)W) continue;
+            const int64_t p = (int64_t)i * W + j;
+            auto U = [&](int r, int c) { return N(s * F[(int64_t)r * W + c], s * dF[(int64_t)r * W + c]); };
+            auto V = [&](int r, int c) { return N(s * F[hw + (int64_t)r * W + c], s * dF[hw + (int64_t)r * W + c]); };
+            auto GU = [&](int r, int c, N val) {
+                const int lr = r - R0, lc = c - C0;
+                if ((unsigned)lr < (unsigned)kAdjTileH && (unsigned)lc < (unsigned)kAdjTileW) {
+                    atomic_add(&acc[0][lr * kAdjTileW + lc], val.v);
+                    atomic_add(&acc[2][lr * kAdjTileW + lc], val.d);
+                }
             };
-            const N f = c == 0 ? u : v;
-            const N dx_back = i > 0 ? f - Cc(i - 1, j) : zero, dx_forw = i + 1 < H ? Cc(i + 1, j) - f : zero;
-            const N dy_back = j > 0 ? f - Cc(i, j - 1) : zero, dy_forw = j + 1 < W ? Cc(i, j + 1) - f : zero;
-            self[c] = self[c] + g;
-            self[0] = self[0] + g * (dx_back * d_dmax0(u) + dx_forw * d_dmin0(u)) * mt;
-            self[1] = self[1] + g * (dy_back * d_dmax0(v) + dy_forw * d_dmin0(v)) * mt;
-            if (i > 0) {
-                self[c] = self[c] + g * mup * mt;
-                GC(i - 1, j, -(g * mup * mt));
-            }
-            if (i + 1 < H) {
-                GC(i + 1, j, g * mun * mt);
-                self[c] = self[c] - g * mun * mt;
-            }
-            if (j > 0) {
-                self[c] = self[c] + g * mvp * mt;
-                GC(i, j - 1, -(g * mvp * mt));
-            }
-            if (j + 1 < W) {
-                GC(i, j + 1, g * mvn * mt);
-                self[c] = self[c] - g * mvn * mt;
+            auto GV = [&](int r, int c, N val) {
+                const int lr = r - R0, lc = c - C0;
+                if ((unsigned)lr < (unsigned)kAdjTileH && (unsigned)lc < (unsigned)kAdjTileW) {
+                    atomic_add(&acc[1][lr * kAdjTileW + lc], val.v);
+                    atomic_add(&acc[3][lr * kAdjTileW + lc], val.d);
+                }
+            };
+            const N u = U(i, j), v = V(i, j), zero;
+            const N gnu(gout[p], dgout[p]), gnv(gout[hw + p], dgout[hw + p]);
+            const T mt = -tau;
+            if (SCHEME == CMAX_SCHEME_BURGERS) {
+                const int ip = i + 1 < H ? i + 1 : H - 1, im = i > 0 ? i - 1 : 0;
+                const int jp = j + 1 < W ? j + 1 : W - 1, jm = j > 0 ? j - 1 : 0;
+                const N uf = U(ip, j), ub = U(im, j), vf = V(i, jp), vb = V(i, jm);
+                const N u_dy_back = j > 0 ? u - U(i, j - 1) : zero, u_dy_forw = j + 1 < W ? U(i, j + 1) - u : zero;
+                const N v_dx_back = i > 0 ? v - V(i - 1, j) : zero, v_dx_forw = i + 1 < H ? V(i + 1, j) - v : zero;
+                const N one((T)1, (T)0);
+                // channel u
+                N self_u = gnu * (one - d_abs(u) * tau);  // d(u|u|/2)/du = |u|
+                GU(im, j, gnu * (-d_max0(ub)) * mt);
+                GU(ip, j, gnu * d_min0(uf) * mt);
+                N self_v = gnu * (u_dy_back * d_dmax0(v) + u_dy_forw * d_dmin0(v)) * mt;
+                const N mvp = d_max0(v), mvn = d_min0(v);
+                if (j > 0) {
+                    self_u = self_u + gnu * mvp * mt;
+                    GU(i, j - 1, -(gnu * mvp * mt));
+                }
+                if (j + 1 < W) {
+                    GU(i, j + 1, gnu * mvn * mt);
+                    self_u = self_u - gnu * mvn * mt;
+                }
+                // channel v
+                self_v = self_v + gnv * (one - d_abs(v) * tau);
+                GV(i, jm, gnv * (-d_max0(vb)) * mt);
+                GV(i, jp, gnv * d_min0(vf) * mt);
+                self_u = self_u + gnv * (v_dx_back * d_dmax0(u) + v_dx_forw * d_dmin0(u)) * mt;
+                const N mup = d_max0(u), mun = d_min0(u);
+                if (i > 0) {
+                    self_v = self_v + gnv * mup * mt;
+                    GV(i - 1, j, -(gnv * mup * mt));
+                }
+                if (i + 1 < H) {
+                    GV(i + 1, j, gnv * mun * mt);
+                    self_v = self_v - gnv * mun * mt;
+                }
+                GU(i, j, self_u);
+                GV(i, j, self_v);
+            } else {
+                const N mup = d_max0(u), mun = d_min0(u), mvp = d_max0(v), mvn = d_min0(v);
+                N self[2];
+                for (int c = 0; c < 2; ++c) {
+                    const N g = c == 0 ? gnu : gnv;
+                    auto Cc = [&](int r, int q) { return c == 0 ? U(r, q) : V(r, q); };
+                    auto GC = [&](int r, int q, N val) {
+                        if (c == 0) GU(r, q, val);
+                        else GV(r, q, val);
+                    };
+                    const N f = c == 0 ? u : v;
+                    const N dx_back = i > 0 ? f - Cc(i - 1, j) : zero, dx_forw = i + 1 < H ? Cc(i + 1, j) - f : zero;
+                    const N dy_back = j > 0 ? f - Cc(i, j - 1) : zero, dy_forw = j + 1 < W ? Cc(i, j + 1) - f : zero;
+                    self[c] = self[c] + g;
+                    self[0] = self[0] + g * (dx_back * d_dmax0(u) + dx_forw * d_dmin0(u)) * mt;
+                    self[1] = self[1] + g * (dy_back * d_dmax0(v) + dy_forw * d_dmin0(v)) * mt;
+                    if (i > 0) {
+                        self[c] = self[c] + g * mup * mt;
+                        GC(i - 1, j, -(g * mup * mt));
+                    }
+                    if (i + 1 < H) {
+                        GC(i + 1, j, g * mun * mt);
+                        self[c] = self[c] - g * mun * mt;
+                    }
+                    if (j > 0) {
+                        self[c] = self[c] + g * mvp * mt;
+                        GC(i, j - 1, -(g * mvp * mt));
+                    }
+                    if (j + 1 < W) {
+                        GC(i, j + 1, g * mvn * mt);
+                        self[c] = self[c] - g * mvn * mt;
+                    }
+                }
+                GU(i, j, self[0]);
+                GV(i, j, self[1]);
             }
         }
-        GU(i, j, self[0]);
-        GV(i, j, self[1]);
+        __syncthreads();
+        for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjThreads) {
+            const int a = q / kAdjTileW, b = q - a * kAdjTileW, i = R0 + a, j = C0 + b;
+            if (i < H && j < W) {
+                const int64_t p = (int64_t)i * W + j;
+                gF[p] += acc[0][q];
+                gF[hw + p] += acc[1][q];
+                dgF[p] += acc[2][q];
+                dgF[hw + p] += acc[3][q];
+            }
+        }
+        __syncthreads();
     }
 }
 
