@@ -15,6 +15,7 @@
 // path is fp32 per event with fp64 reductions as everywhere in cmax_fused.hip.
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <vector>
 
 #include "cmax_common.h"
@@ -76,7 +77,8 @@ struct FinalParams {
 constexpr int kTailLds = 4096;  // patch-grid values staged in LDS by k_patch_tail (2 x 45 x 45 patches)
 __global__ void __launch_bounds__(256)
 k_patch_tail(FinalParams fp, const double *__restrict__ results, const double *__restrict__ x, const double *__restrict__ gx64,
-             const float *__restrict__ gx32, const double *__restrict__ gscale_dev, double *__restrict__ out) {
+             const float *__restrict__ gx32, const double *__restrict__ gscale_dev, double *__restrict__ out,
+             unsigned long long *__restrict__ seq_dev) {
     __shared__ double smem[4];
     __shared__ double s_tv;
     __shared__ double s_x[kTailLds];
@@ -146,6 +148,15 @@ k_patch_tail(FinalParams fp, const double *__restrict__ results, const double *_
         }
         out[1 + p] = g;
     }
+    // completion flag for a host that polls the (pinned) output instead of sleeping in hipStreamSynchronize: a run
+    // counter, written after every result of this launch is visible system-wide
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long v = seq_dev[0] + 1ull;
+        seq_dev[0] = v;
+        reinterpret_cast<volatile unsigned long long *>(out + 1 + fp.nx)[0] = v;
+    }
 }
 
 }  // namespace cmax
@@ -162,7 +173,9 @@ struct cmax_patch_plan_s {
     double *dflow64 = nullptr, *dvox64 = nullptr, *dgacc64 = nullptr, *dgflow64 = nullptr, *scal = nullptr;
     float *motion32 = nullptr, *grad32 = nullptr, *tan32 = nullptr, *gx32 = nullptr;
     double *h_out_dev = nullptr;  // device view of the pinned output: the tail kernel writes the result there
-    double *h_in = nullptr, *h_out = nullptr;  // pinned staging: x | v | 2 scalars, loss | grad
+    double *h_in = nullptr, *h_out = nullptr;  // pinned staging: x | v | 2 scalars, loss | grad | run counter
+    unsigned long long *seq_dev = nullptr;     // device-side run counter of the tail kernel
+    unsigned long long seq_seen = 0;           // its value after the last completed call
     // Captured launch sequences (hipGraph), replayed on the plan's own stream: an evaluation is ~25 small launches,
     // host-bound when issued one by one.  Keyed by everything that changes the sequence: the kind of call and the
     // handle's host-side state (which vote buffer is current, which images are already zero, whether the
@@ -281,7 +294,7 @@ int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t 
     for (int i = 0; i < 4; ++i) fp.weight[i] = d.weight[i];
     fp.tv_weight = d.tv_weight;
     fp.gscale = d.t_scale * wscale;  // d(flow * t_scale) / d flow
-    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, gx64, gx32, (const double *)nullptr, p->h_out_dev);
+    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, gx64, gx32, (const double *)nullptr, p->h_out_dev, p->seq_dev);
     CMAX_CHECK_LAUNCH();
     return 0;
 }
@@ -340,7 +353,7 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
     for (int i = 0; i < 4; ++i) fp.weight[i] = 0.0;
     fp.tv_weight = 0.0;
     fp.gscale = d.t_scale;  // the outer t P^T; times |v|_inf from device memory
-    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, p->gx64, (const float *)nullptr, vmax, p->h_out_dev);
+    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, p->gx64, (const float *)nullptr, vmax, p->h_out_dev, p->seq_dev);
     CMAX_CHECK_LAUNCH();
     return 0;
 }
@@ -381,7 +394,7 @@ int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
     for (int i = 0; i < 4; ++i) fp.weight[i] = 0.0;
     fp.tv_weight = 0.0;
     fp.gscale = d.t_scale * d.t_scale * wscale;  // H_x = t^2 P^T H_flow P (times |v|_inf, from device memory)
-    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, gx64, gx32, vmax, p->h_out_dev);
+    hipLaunchKernelGGL(k_patch_tail, dim3(1), dim3(256), 0, s, fp, p->results, p->x64, gx64, gx32, vmax, p->h_out_dev, p->seq_dev);
     CMAX_CHECK_LAUNCH();
     return 0;
 }
@@ -405,6 +418,30 @@ void drop_graphs(cmax_patch_plan_s *p) {
     p->graphs.clear();
 }
 
+// The tail kernel bumps a run counter in the pinned output after its results are visible.  Polling it returns as
+// soon as the graph's last kernel has written, without the sleep / wake-up of hipStreamSynchronize.
+static volatile unsigned long long *plan_flag(cmax_patch_plan_s *p) {
+    return reinterpret_cast<volatile unsigned long long *>(p->h_out + 1 + p->nx);
+}
+
+static int wait_for_tail(cmax_patch_plan_s *p, hipStream_t s, bool poll) {
+    const unsigned long long expected = p->seq_seen + 1ull;
+    if (poll) {
+        volatile unsigned long long *flag = plan_flag(p);
+        for (long spin = 0; spin < 4000000L; ++spin) {  // a few ms at most, then sleep like everybody else
+            if (*flag == expected) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                p->seq_seen = expected;
+                return 0;
+            }
+            __builtin_ia32_pause();
+        }
+    }
+    CMAX_CHECK_HIP(hipStreamSynchronize(s));
+    p->seq_seen = *plan_flag(p);
+    return 0;
+}
+
 // Runs `enqueue(stream)` and waits for its result: eagerly on the caller's stream for the first calls (and whenever
 // the handle is being profiled or a capture failed), afterwards as a captured hipGraph replayed on the plan's stream.
 template <typename F>
@@ -420,8 +457,7 @@ int run_sequence(cmax_patch_plan_s *p, int kind, hipStream_t caller, F enqueue) 
         ++p->eager_calls;
         int rc = enqueue(caller);
         if (rc) return rc;
-        CMAX_CHECK_HIP(hipStreamSynchronize(caller));
-        return 0;
+        return wait_for_tail(p, caller, false);
     }
     const uint64_t key = state_key(pre, kind);
     cmax_patch_plan_s::GraphEntry *entry = nullptr;
@@ -445,8 +481,7 @@ int run_sequence(cmax_patch_plan_s *p, int kind, hipStream_t caller, F enqueue) 
             handle_set_eval_state(p->handle, &pre);
             rc = enqueue(caller);
             if (rc) return rc;
-            CMAX_CHECK_HIP(hipStreamSynchronize(caller));
-            return 0;
+            return wait_for_tail(p, caller, false);
         }
         cmax_patch_plan_s::GraphEntry e;
         e.key = key;
@@ -462,8 +497,7 @@ int run_sequence(cmax_patch_plan_s *p, int kind, hipStream_t caller, F enqueue) 
     CMAX_CHECK_HIP(hipEventRecord(p->ev_caller, caller));
     CMAX_CHECK_HIP(hipStreamWaitEvent(p->own_stream, p->ev_caller, 0));
     CMAX_CHECK_HIP(hipGraphLaunch(entry->exec, p->own_stream));
-    CMAX_CHECK_HIP(hipStreamSynchronize(p->own_stream));
-    return 0;
+    return wait_for_tail(p, p->own_stream, true);
 }
 
 }  // namespace
@@ -508,11 +542,14 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     if (!rc && hipHostMalloc((void **)&p->h_in, (2 * (size_t)p->nx + 2) * sizeof(double)) != hipSuccess) rc = CMAX_ENOMEM;
     if (!rc && hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) rc = CMAX_ENOMEM;
     if (!rc && hipEventCreateWithFlags(&p->ev_caller, hipEventDisableTiming) != hipSuccess) rc = CMAX_ENOMEM;
-    if (!rc && hipHostMalloc((void **)&p->h_out, (1 + (size_t)p->nx) * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc && hipHostMalloc((void **)&p->h_out, (2 + (size_t)p->nx) * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = CMAX_ENOMEM;
     if (!rc && hipHostGetDevicePointer((void **)&p->h_out_dev, p->h_out, 0) != hipSuccess) {
         (void)hipGetLastError();
         p->h_out_dev = p->h_out;  // unified addressing: pinned host memory is addressable from the device as it is
     }
+    if (!rc) rc = plan_alloc(&p->seq_dev, 1);
+    if (!rc && hipMemset(p->seq_dev, 0, sizeof(unsigned long long)) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc) reinterpret_cast<unsigned long long *>(p->h_out + 1 + p->nx)[0] = 0ull;
     if (rc) {
         if (rc == CMAX_ENOMEM) set_error("patch_plan_create: allocation failed");
         cmax_patch_plan_destroy(p);
@@ -542,6 +579,7 @@ int cmax_patch_plan_destroy(cmax_patch_plan_t p) {
         if (q) (void)hipFree(q);
     if (p->h_in) (void)hipHostFree(p->h_in);
     if (p->h_out) (void)hipHostFree(p->h_out);
+    if (p->seq_dev) (void)hipFree(p->seq_dev);
     delete p;
     return 0;
 }
