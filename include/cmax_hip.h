@@ -307,8 +307,9 @@ typedef struct cmax_patch_plan_s *cmax_patch_plan_t;
 int cmax_sizeof_patch_objective(void);
 int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc_host, cmax_patch_plan_t *out);
 int cmax_patch_plan_destroy(cmax_patch_plan_t plan);
-/* Introspection for tests: evaluations after the first few are replayed from captured hipGraphs (one per
- * distinct launch sequence); *graph_replay_enabled = 0 if a capture failed and the plan launches eagerly.  */
+/* Introspection for tests.  Default: every evaluation is launched eagerly (*graph_replay_enabled = 0).  With
+ * CMAX_PLAN_GRAPHS=1 in the environment at plan creation, evaluations after the first few are replayed from
+ * captured hipGraphs (one per distinct launch sequence; 0 again if a capture failed).                        */
 int cmax_patch_plan_info(cmax_patch_plan_t plan, int *n_graphs, int *graph_replay_enabled);
 /* x_host [2*ph*pw] -> *loss_host, grad_host [2*ph*pw] (NULL: value only).  with_tv = 0 leaves the
  * total_variation term out (the smooth part, differenced for time-aware Hessian-vector products).
