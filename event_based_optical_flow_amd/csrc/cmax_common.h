@@ -57,6 +57,9 @@ struct HandleEvalState {
 };
 __attribute__((visibility("hidden"))) void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out);
 __attribute__((visibility("hidden"))) void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in);
+// cmax_flow.hip, for the patch plan: fp64 voxel and (when the single-launch tiled chain ran: *wrote_v32) its fp32 copy
+__attribute__((visibility("hidden"))) int voxel_construct_f64_f32(const double *F, int Tn, int t0, int H, int W, int scheme, double *V,
+                                                               float *V32, bool *wrote_v32, hipStream_t s);
 
 // ---- wave / block reductions (64-wide) -------------------------------------------------------
 // DPP on the VALU instead of ds_bpermute shuffles (~16 cycles each on gfx950): 4 row shifts, then lane 15 of

@@ -80,7 +80,8 @@ constexpr int kVoxTileH = 16, kVoxTileW = 32;  // 260 x 346: 17 x 11 = 187 workg
 constexpr int kVoxThreads = 1024;                // about one patch cell per thread and step: the chain is a sequence of barriers
 
 template <typename T, int SCHEME>
-__global__ void __launch_bounds__(kVoxThreads) k_voxel_chain_tiled(const T *__restrict__ F, int Tn, int t0, int H, int W, T tau, int S, T *__restrict__ Vox) {
+__global__ void __launch_bounds__(kVoxThreads) k_voxel_chain_tiled(const T *__restrict__ F, int Tn, int t0, int H, int W, T tau, int S, T *__restrict__ Vox,
+                                                                    float *__restrict__ Vox32) {
     extern __shared__ unsigned char s_raw[];
     T *buf = reinterpret_cast<T *>(s_raw);
     const int ph = kVoxTileH + 2 * S, pw = kVoxTileW + 2 * S, cells = ph * pw;  // the patch
@@ -105,6 +106,10 @@ __global__ void __launch_bounds__(kVoxThreads) k_voxel_chain_tiled(const T *__re
             if (dir == 0 && in && in_tile(a, b)) {
                 Vox[(int64_t)t0 * sz + (int64_t)r * W + c] = cur[q];
                 Vox[(int64_t)t0 * sz + hw + (int64_t)r * W + c] = cur[cells + q];
+                if (Vox32) {  // the fp32 motion of the fused objective, written on the way
+                    Vox32[(int64_t)t0 * sz + (int64_t)r * W + c] = (float)cur[q];
+                    Vox32[(int64_t)t0 * sz + hw + (int64_t)r * W + c] = (float)cur[cells + q];
+                }
             }
         }
         __syncthreads();
@@ -125,6 +130,10 @@ __global__ void __launch_bounds__(kVoxThreads) k_voxel_chain_tiled(const T *__re
                 if (in_tile(a, b)) {
                     Vox[(int64_t)bin * sz + (int64_t)r * W + c] = nu;
                     Vox[(int64_t)bin * sz + hw + (int64_t)r * W + c] = nv;
+                    if (Vox32) {
+                        Vox32[(int64_t)bin * sz + (int64_t)r * W + c] = (float)nu;
+                        Vox32[(int64_t)bin * sz + hw + (int64_t)r * W + c] = (float)nv;
+                    }
                 }
             }
             __syncthreads();
@@ -348,7 +357,8 @@ static int flow_step_adj(const T *F, int H, int W, double dt, int scheme, const 
 // the torch loop's stray extra backward iteration, 138-139, is not reproduced).  Step j of both time directions
 // (and, with j = 1, the copy of F into bin t0) share a launch.
 template <typename T>
-int voxel_construct(const T *F, int Tn, int t0, int H, int W, int scheme, T *V, hipStream_t s) {
+int voxel_construct(const T *F, int Tn, int t0, int H, int W, int scheme, T *V, hipStream_t s, float *V32 = nullptr, bool *wrote_v32 = nullptr) {
+    if (wrote_v32) *wrote_v32 = false;
     const int64_t sz = 2 * (int64_t)H * W;
     const T tau = (T)(1.0 / (double)Tn);
     const int grid = div_up((int64_t)H * W, 256);
@@ -362,10 +372,11 @@ int voxel_construct(const T *F, int Tn, int t0, int H, int W, int scheme, T *V, 
         if (lds <= 60 * 1024) {
             const int tiles = div_up(H, kVoxTileH) * div_up(W, kVoxTileW);
             if (scheme == CMAX_SCHEME_BURGERS)
-                hipLaunchKernelGGL((k_voxel_chain_tiled<T, CMAX_SCHEME_BURGERS>), dim3(tiles), dim3(kVoxThreads), lds, s, F, Tn, t0, H, W, tau, nstep, V);
+                hipLaunchKernelGGL((k_voxel_chain_tiled<T, CMAX_SCHEME_BURGERS>), dim3(tiles), dim3(kVoxThreads), lds, s, F, Tn, t0, H, W, tau, nstep, V, V32);
             else
-                hipLaunchKernelGGL((k_voxel_chain_tiled<T, CMAX_SCHEME_UPWIND>), dim3(tiles), dim3(kVoxThreads), lds, s, F, Tn, t0, H, W, tau, nstep, V);
+                hipLaunchKernelGGL((k_voxel_chain_tiled<T, CMAX_SCHEME_UPWIND>), dim3(tiles), dim3(kVoxThreads), lds, s, F, Tn, t0, H, W, tau, nstep, V, V32);
             CMAX_CHECK_LAUNCH();
+            if (wrote_v32) *wrote_v32 = V32 != nullptr;
             return 0;
         }
     }
@@ -432,7 +443,7 @@ int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T 
             hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_UPWIND>), agrid, dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
         CMAX_CHECK_LAUNCH();
     }
-    CMAX_CHECK_HIP(hipMemcpyAsync(gF, gV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (gF) CMAX_CHECK_HIP(hipMemcpyAsync(gF, gV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -500,12 +511,19 @@ int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int 
     return 0;
 }
 
-template int voxel_construct<float>(const float *, int, int, int, int, int, float *, hipStream_t);
+template int voxel_construct<float>(const float *, int, int, int, int, int, float *, hipStream_t, float *, bool *);
 template int voxel_construct_adj<float>(const float *, int, int, int, int, int, float *, float *, hipStream_t);
 
 }  // namespace cmax
 
 using namespace cmax;
+
+namespace cmax {
+// plan-internal: fp64 voxel and, when the tiled kernel ran, its fp32 copy in the same launch (*wrote_v32)
+int voxel_construct_f64_f32(const double *F, int Tn, int t0, int H, int W, int scheme, double *V, float *V32, bool *wrote_v32, hipStream_t s) {
+    return voxel_construct<double>(F, Tn, t0, H, W, scheme, V, s, V32, wrote_v32);
+}
+}  // namespace cmax
 
 extern "C" {
 
@@ -539,7 +557,7 @@ int cmax_voxel_construct(const void *F, int dtype, int Tn, int t0, int H, int W,
 
 int cmax_voxel_construct_adj(const void *V, int dtype, int Tn, int t0, int H, int W, int scheme, void *gV, void *gF,
                              cmax_stream_t stream) {
-    CMAX_REQUIRE(V && gV && gF && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj");
+    CMAX_REQUIRE(V && gV && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj");
     CMAX_REQUIRE(scheme == CMAX_SCHEME_BURGERS || scheme == CMAX_SCHEME_UPWIND, "voxel_construct_adj: scheme");
     if (dtype == CMAX_F32) return voxel_construct_adj<float>((const float *)V, Tn, t0, H, W, scheme, (float *)gV, (float *)gF, (hipStream_t)stream);
     if (dtype == CMAX_F64) return voxel_construct_adj<double>((const double *)V, Tn, t0, H, W, scheme, (double *)gV, (double *)gF, (hipStream_t)stream);

@@ -218,6 +218,21 @@ int forward_motion(cmax_patch_plan_s *p, const double *src64, double scale, cons
         CMAX_CHECK_LAUNCH();
         return 0;
     }
+    if (d.time_aware && !scale_dev) {
+        // patch grid -> fp64 displacement field (x t_scale) in one kernel; the voxel is built on the displacement
+        // field (patch_contrast_pyramid.py:452, 499-515) and leaves the chain kernel in fp64 and fp32 at once
+        hipLaunchKernelGGL((k_patch_to_dense<double, double>), dim3(grid), dim3(256), 0, s, src64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w,
+                           d.H, d.W, p->flow64, scale);
+        CMAX_CHECK_LAUNCH();
+        bool wrote32 = false;
+        int rc = voxel_construct_f64_f32(p->flow64, d.T, d.t0, d.H, d.W, d.scheme, p->vox64, dst32, &wrote32, s);
+        if (rc) return rc;
+        if (!wrote32) {
+            hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->vox64, p->nmotion, 1.0, (const double *)nullptr, dst32);
+            CMAX_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     int rc = cmax_patch_to_dense(src64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 0, p->flow64, s);
     if (rc) return rc;
     if (!d.time_aware) {
@@ -227,7 +242,6 @@ int forward_motion(cmax_patch_plan_s *p, const double *src64, double scale, cons
     }
     hipLaunchKernelGGL((k_convert_scale<double, double>), dim3(grid), dim3(256), 0, s, p->flow64, p->nflow, scale, scale_dev, p->flow64);
     CMAX_CHECK_LAUNCH();
-    // the voxel is built on the displacement field (patch_contrast_pyramid.py:452, 499-515)
     rc = cmax_voxel_construct(p->flow64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->vox64, s);
     if (rc) return rc;
     hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->vox64, p->nmotion, 1.0, (const double *)nullptr, dst32);
@@ -251,10 +265,10 @@ int backward_motion(cmax_patch_plan_s *p, const double **gx64, const float **gx3
         return 0;
     }
     const double *gflow = p->gacc64;
-    if (d.time_aware) {
-        int rc = cmax_voxel_construct_adj(p->vox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->gflow64, s);
+    if (d.time_aware) {  // the sweep leaves dL/dF in bin t0 of the gradient voxel: read it there
+        int rc = cmax_voxel_construct_adj(p->vox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, nullptr, s);
         if (rc) return rc;
-        gflow = p->gflow64;
+        gflow = p->gacc64 + (int64_t)d.t0 * p->nflow;
     }
     int rc = cmax_patch_to_dense(gflow, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
     if (rc) return rc;

@@ -146,7 +146,8 @@ int cmax_flow_step_adj(const void *F, int dtype, int H, int W, double dt, int sc
                        const void *gout, void *gF, cmax_stream_t stream);
 
 /* construct_dense_flow_voxel_torch (src/utils/flow_utils.py:99-161): V[T,2,H,W] from F at bin
- * t0 (0 = "first", T/2 = "middle"); and its adjoint (gV is clobbered, gF[2,H,W] overwritten).  */
+ * t0 (0 = "first", T/2 = "middle"); and its adjoint (gV is clobbered: the sweep leaves dL/dF in
+ * its bin t0; gF[2,H,W] receives a copy, NULL: no copy).                                        */
 int cmax_voxel_construct(const void *F, int dtype, int T, int t0, int H, int W, int scheme, void *V,
                          cmax_stream_t stream);
 int cmax_voxel_construct_adj(const void *V, int dtype, int T, int t0, int H, int W, int scheme,
