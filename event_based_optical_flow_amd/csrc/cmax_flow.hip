@@ -500,10 +500,12 @@ int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int 
             jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.gout[n] = gV + b; jobs.dgout[n] = dgV + b; jobs.dst[n] = gV + a; jobs.ddst[n] = dgV + a;
             jobs.s[n++] = (T)-1;
         }
+        // the two chains write different bins until the last step, where both arrive at bin t0
+        const dim3 dgrid(div_up(H, kAdjTileH) * div_up(W, kAdjTileW), (n == 2 && jobs.dst[0] != jobs.dst[1]) ? 2 : 1);
         if (scheme == CMAX_SCHEME_BURGERS)
-            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_BURGERS>), dim3(div_up(H, kAdjTileH) * div_up(W, kAdjTileW)), dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
+            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_BURGERS>), dgrid, dim3(kAdjDualThreads), 0, s, jobs, n, H, W, tau);
         else
-            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_UPWIND>), dim3(div_up(H, kAdjTileH) * div_up(W, kAdjTileW)), dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
+            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_UPWIND>), dgrid, dim3(kAdjDualThreads), 0, s, jobs, n, H, W, tau);
         CMAX_CHECK_LAUNCH();
     }
     if (gF) CMAX_CHECK_HIP(hipMemcpyAsync(gF, gV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));

@@ -101,11 +101,12 @@ __global__ void __launch_bounds__(256) k_flow_step_dual(DualJobs<T> jobs, int H,
 // one workgroup owns a 16 x 32 tile of the destination, evaluates the scatter of the tile's pixels and of the ring
 // around it, keeps what lands inside the tile in LDS and adds it to the destination with plain read-modify-writes.
 constexpr int kAdjTileH = 16, kAdjTileW = 32, kAdjThreads = 1024;
+constexpr int kAdjDualThreads = 512;  // dual numbers: twice the registers; two workgroups per CU run the two time directions side by side
 
 // adjoint step on dual numbers, scatter form like flow_step_adj_core: F -> (V_i, dV_i), upstream (lambda, dlambda).
 // The jobs of a launch (both time directions) run one after the other in the workgroup.
 template <typename T, int SCHEME>
-__global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_dual(DualJobs<T> jobs, int n_jobs, int H, int W, T tau) {
+__global__ void __launch_bounds__(kAdjDualThreads) k_flow_step_adj_dual(DualJobs<T> jobs, int n_jobs, int H, int W, T tau) {
     using N = Dual<T>;
     __shared__ T acc[4][kAdjTileH * kAdjTileW];  // lambda u, lambda v, dlambda u, dlambda v
     const int64_t hw = (int64_t)H * W;
@@ -113,13 +114,15 @@ __global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_dual(DualJobs<T> 
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int R0 = tr * kAdjTileH, C0 = tc * kAdjTileW;
     constexpr int RH = kAdjTileH + 2, RW = kAdjTileW + 2;
-    for (int y = 0; y < n_jobs; ++y) {
+    // gridDim.y > 1: one job per workgroup (different destinations); else the jobs one after the other
+    const int y_first = gridDim.y > 1 ? (int)blockIdx.y : 0, y_last = gridDim.y > 1 ? (int)blockIdx.y + 1 : n_jobs;
+    for (int y = y_first; y < y_last; ++y) {
         const T *F = jobs.src[y], *dF = jobs.dsrc[y], *gout = jobs.gout[y], *dgout = jobs.dgout[y];
         T *gF = jobs.dst[y], *dgF = jobs.ddst[y];
         const T s = jobs.s[y];
-        for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjThreads) acc[0][q] = acc[1][q] = acc[2][q] = acc[3][q] = (T)0;
+        for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjDualThreads) acc[0][q] = acc[1][q] = acc[2][q] = acc[3][q] = (T)0;
         __syncthreads();
-        for (int q = threadIdx.x; q < RH * RW; q += kAdjThreads) {
+        for (int q = threadIdx.x; q < RH * RW; q += kAdjDualThreads) {
             const int a = q / RW, b = q - a * RW, i = R0 - 1 + a, j = C0 - 1 + b;
             if ((unsigned)i >= (unsigned)H || (unsigned)j >= (unsigned)W) continue;
             const int64_t p = (int64_t)i * W + j;
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_dual(DualJobs<T> 
             }
         }
         __syncthreads();
-        for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjThreads) {
+        for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjDualThreads) {
             const int a = q / kAdjTileW, b = q - a * kAdjTileW, i = R0 + a, j = C0 + b;
             if (i < H && j < W) {
                 const int64_t p = (int64_t)i * W + j;

@@ -44,14 +44,15 @@ k_accumulate(const float *__restrict__ g, int64_t n, double w, int first, double
 
 // max |x| as the bit pattern of a non-negative double (order-preserving under unsigned compare); *bits zeroed by the caller
 __global__ void __launch_bounds__(256) k_absmax(const double *__restrict__ x, int64_t n, unsigned long long *__restrict__ bits) {
-    __shared__ unsigned long long s_m;
-    if (threadIdx.x == 0) s_m = 0ull;
-    __syncthreads();
+    __shared__ double s_m[256 / kWave];
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(x[i]));
-    atomicMax(&s_m, (unsigned long long)__double_as_longlong(m));
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) s_m[threadIdx.x / kWave] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(bits, s_m);
+    // one atomic per workgroup (and few workgroups): equal-address atomics serialise at ~12 ns each
+    if (threadIdx.x == 0) atomicMax(bits, (unsigned long long)__double_as_longlong(fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]))));
 }
 
 // scal[0] = max (1 if the field is all zero), scal[1] = 1 / scal[0]
@@ -338,7 +339,7 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
     // fp32 motion and unit-norm fp32 tangent of the fused terms
     unsigned long long *bits = reinterpret_cast<unsigned long long *>(p->scal + 2);
     CMAX_CHECK_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_absmax, dim3(mgrid < 512 ? mgrid : 512), dim3(256), 0, s, p->dvox64, p->nmotion, bits);
+    hipLaunchKernelGGL(k_absmax, dim3(mgrid < 256 ? mgrid : 256), dim3(256), 0, s, p->dvox64, p->nmotion, bits);
     hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(1), 0, s, bits, p->scal);
     hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(mgrid), dim3(256), 0, s, p->vox64, p->nmotion, 1.0, (const double *)nullptr, p->motion32);
     hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(mgrid), dim3(256), 0, s, p->dvox64, p->nmotion, 1.0, p->scal + 1, p->tan32);
