@@ -434,9 +434,9 @@ int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T 
             jobs.s[n++] = (T)-1;
         }
         const int tiles = div_up(H, kAdjTileH) * div_up(W, kAdjTileW);
-        // one workgroup runs both jobs of its tile one after the other: 2 x 187 workgroups of 1024 threads would need two
-        // rounds on 256 CUs (measured 10.0 vs 8.8 us), and at the last step both chains write bin t0 anyway
-        const dim3 agrid(tiles, 1);
+        // the two chains write different bins until the last step, where both arrive at bin t0 (then one workgroup
+        // runs both jobs of its tile one after the other)
+        const dim3 agrid(tiles, (n == 2 && jobs.dst[0] != jobs.dst[1]) ? 2 : 1);
         if (scheme == CMAX_SCHEME_BURGERS)
             hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_BURGERS>), agrid, dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
         else

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) k_flow_step_dual(DualJobs<T> jobs, int H,
 // Tile geometry of the atomic-free adjoint steps (k_flow_step_adj_tiled in cmax_flow.hip and the dual version below):
 // one workgroup owns a 16 x 32 tile of the destination, evaluates the scatter of the tile's pixels and of the ring
 // around it, keeps what lands inside the tile in LDS and adds it to the destination with plain read-modify-writes.
-constexpr int kAdjTileH = 16, kAdjTileW = 32, kAdjThreads = 1024;
+constexpr int kAdjTileH = 16, kAdjTileW = 32, kAdjThreads = 512;
 constexpr int kAdjDualThreads = 512;  // dual numbers: twice the registers; two workgroups per CU run the two time directions side by side
 
 // adjoint step on dual numbers, scatter form like flow_step_adj_core: F -> (V_i, dV_i), upstream (lambda, dlambda).
