@@ -63,7 +63,8 @@ __global__ void k_absmax_finish(const unsigned long long *__restrict__ bits, dou
 }
 
 struct FinalParams {
-    int n_terms, with_tv, nx;
+    int n_terms, with_tv, nx;  // nx = 0: value only
+    int flag_slot;             // index (in doubles) of the run counter in the output: 1 + the plan's nx, whatever this call's nx is
     int ph, pw, tv_crop;       // patch grid of the total-variation term
     double weight[4], tv_weight, gscale;
 };
@@ -156,7 +157,7 @@ k_patch_tail(FinalParams fp, const double *__restrict__ results, const double *_
     if (threadIdx.x == 0) {
         const unsigned long long v = seq_dev[0] + 1ull;
         seq_dev[0] = v;
-        reinterpret_cast<volatile unsigned long long *>(out + 1 + fp.nx)[0] = v;
+        reinterpret_cast<volatile unsigned long long *>(out + fp.flag_slot)[0] = v;
     }
 }
 
@@ -301,6 +302,7 @@ int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t 
     }
     FinalParams fp;
     fp.n_terms = d.n_terms;
+    fp.flag_slot = 1 + (int)p->nx;
     fp.with_tv = tv ? 1 : 0;
     fp.nx = want_grad ? p->nx : 0;
     fp.ph = d.ph;
@@ -360,6 +362,7 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
     if (rc) return rc;
     FinalParams fp;
     fp.n_terms = 0;
+    fp.flag_slot = 1 + (int)p->nx;
     fp.with_tv = 0;  // total_variation is piecewise linear: zero Hessian almost everywhere
     fp.nx = p->nx;
     fp.ph = d.ph;
@@ -401,6 +404,7 @@ int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
     if (rc) return rc;
     FinalParams fp;
     fp.n_terms = 0;
+    fp.flag_slot = 1 + (int)p->nx;
     fp.with_tv = 0;  // total_variation is piecewise linear: zero Hessian almost everywhere
     fp.nx = p->nx;
     fp.ph = d.ph;

@@ -435,3 +435,27 @@ def test_pyramid_reinitialisation_finds_the_patch_motion(golden):
     few[:, 0], few[:, 1] = 3.0, 4.0
     handle2 = E.CMaxHandle((H, W)).set_events(few)
     np.testing.assert_array_equal(slv.initialize_guess_from_patch_search(handle2, 2, m0.reshape(-1)), m0.reshape(-1))
+
+
+def test_native_plan_value_only_calls_complete_promptly(golden):
+    """The plan returns when the tail kernel's run counter appears in the pinned output; a value-only call (no gradient
+    written) must find it in the same slot -- a wrong slot is only caught by the poll's time-out (~0.2 s per call)."""
+    import time
+
+    g = golden("solver_objective")
+    k = "plain_s3"
+    size = tuple(int(v) for v in g["image_size"])
+    ev = g["events"]
+    h = E.CMaxHandle(size).set_events(ev)
+    obj = PatchFlowObjective(h, ev[:, 2].max() - ev[:, 2].min(), g[k + "__patch_image_size"], g[k + "__patch_size"], g[k + "__sliding_window"],
+                             g["plain__patch_shift"], cost="hybrid", cost_with_weight=YAML_HYBRID, blur_sigma=1)
+    x = np.asarray(g[k + "__x"], dtype=np.float64).reshape(-1)
+    l_ref, _ = obj.value_and_grad_numpy(x)
+    for _ in range(3):
+        obj.value_and_grad_numpy(x, want_grad=False)
+    t0 = time.perf_counter()
+    for i in range(30):
+        lv, gv = obj.value_and_grad_numpy(x, want_grad=(i % 3 == 0), with_tv=(i % 2 == 0))
+        if i % 2 == 0:
+            assert abs(lv - l_ref) <= 1e-9 * abs(l_ref)
+    assert time.perf_counter() - t0 < 0.5, time.perf_counter() - t0
