@@ -119,6 +119,7 @@ SIGNATURES = {
     "cmax_patch_plan_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cmax_patch_plan_evaluate": (c_int, [c_vp, c_vp, c_int, ctypes.POINTER(c_dbl), c_vp, c_vp]),
     "cmax_patch_plan_hvp": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "cmax_patch_plan_set_t_scale": (c_int, [c_vp, c_dbl]),
     "cmax_patch_search": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_dbl, c_vp, c_vp, c_vp]),
 }
 

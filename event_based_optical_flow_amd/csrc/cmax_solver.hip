@@ -583,6 +583,16 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     return 0;
 }
 
+int cmax_patch_plan_set_t_scale(cmax_patch_plan_t p, double t_scale) {
+    CMAX_REQUIRE(p != nullptr, "patch_plan_set_t_scale");
+    if (p->d.t_scale != t_scale) {
+        p->d.t_scale = t_scale;
+        drop_graphs(p);  // the scale is baked into captured launches
+        p->eager_calls = 0;
+    }
+    return 0;
+}
+
 int cmax_patch_plan_info(cmax_patch_plan_t p, int *n_graphs, int *graph_replay_enabled) {
     CMAX_REQUIRE(p && n_graphs && graph_replay_enabled, "patch_plan_info");
     *n_graphs = (int)p->graphs.size();

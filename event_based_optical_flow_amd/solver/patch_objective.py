@@ -87,6 +87,12 @@ class PatchFlowObjective:
             except Exception:  # interpreter shutdown
                 pass
 
+    def set_t_scale(self, t_scale: float):
+        """The next batch behind the same handle has another duration (a solver keeps its objectives across frames)."""
+        self.t_scale = float(t_scale)
+        if self._plan is not None:
+            _lib.check(_lib.load().cmax_patch_plan_set_t_scale(self._plan, self.t_scale))
+
     def native_plan_info(self):
         """(number of captured hipGraphs, graph replay enabled) of the native plan."""
         n, ok = ctypes.c_int(0), ctypes.c_int(0)

@@ -111,6 +111,8 @@ class PyramidalPatchContrastMaximization:
         self.previous_frame_best_estimation: Optional[Dict[int, np.ndarray]] = None
         self.history = []  # (scale, OptimizeResult)
         self.search_history = []  # (scale, candidates, loss, picked index) of the per-patch re-initialisation
+        self._handle: Optional[CMaxHandle] = None
+        self._objectives: Dict[int, PatchFlowObjective] = {}
 
     # -- reference API ---------------------------------------------------------------------------
     def set_previous_frame_best_estimation(self, previous_best):
@@ -126,7 +128,11 @@ class PyramidalPatchContrastMaximization:
     def optimize(self, events: np.ndarray) -> Dict[int, np.ndarray]:
         """events [n,4] (x row, y col, t, p) -> {scale: motion [2, ph, pw]} in pixel per time unit."""
         logger.info(f"DoF is {self.motion_vector_size * self.total_n_patch}")
-        handle = CMaxHandle(self.image_shape, self.padding).set_events(events, time_bin=self.time_bin)
+        # one handle and one objective per scale for the life of the solver: the device workspaces, the sorted-event
+        # buffers and the native plans are reused from frame to frame (main.py runs one solver over a whole sequence)
+        if self._handle is None:
+            self._handle = CMaxHandle(self.image_shape, self.padding)
+        handle = self._handle.set_events(events, time_bin=self.time_bin)
         t = events[:, 2]
         t_scale = float(t.max() - t.min()) if self.normalize_t_in_batch else 1.0
         best: Dict[int, np.ndarray] = {}
@@ -134,11 +140,15 @@ class PyramidalPatchContrastMaximization:
         self.search_history = []
         for s in range(self.coarest_scale, self.patch_scales):
             pis = self.scaled_patch_image_size[s]
-            objective = PatchFlowObjective(
-                handle, t_scale, pis, self.scaled_patch_size[s], self.scaled_patch_size[s], self.patch_shift,
-                cost=self.cost_name, cost_with_weight=self.cost_weight, blur_sigma=self.iwe_config["blur_sigma"],
-                time_aware=self.is_time_aware, time_bin=self.time_bin, flow_interpolation=self.flow_interpolation,
-                t0_flow_location=self.t0_flow_location, filter_type=self.filter_type)
+            objective = self._objectives.get(s)
+            if objective is None:
+                objective = self._objectives[s] = PatchFlowObjective(
+                    handle, t_scale, pis, self.scaled_patch_size[s], self.scaled_patch_size[s], self.patch_shift,
+                    cost=self.cost_name, cost_with_weight=self.cost_weight, blur_sigma=self.iwe_config["blur_sigma"],
+                    time_aware=self.is_time_aware, time_bin=self.time_bin, flow_interpolation=self.flow_interpolation,
+                    t0_flow_location=self.t0_flow_location, filter_type=self.filter_type)
+            else:
+                objective.set_t_scale(t_scale)
             if self.previous_frame_best_estimation is not None and s == self.coarest_scale:
                 x0 = np.copy(self.previous_frame_best_estimation[s]).reshape(-1)
             elif s > self.coarest_scale:

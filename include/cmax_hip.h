@@ -308,6 +308,8 @@ typedef struct cmax_patch_plan_s *cmax_patch_plan_t;
 int cmax_sizeof_patch_objective(void);
 int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc_host, cmax_patch_plan_t *out);
 int cmax_patch_plan_destroy(cmax_patch_plan_t plan);
+/* A plan outlives a batch: the next batch behind the same handle (cmax_set_events) usually has another duration.  */
+int cmax_patch_plan_set_t_scale(cmax_patch_plan_t plan, double t_scale);
 /* Introspection for tests.  Default: every evaluation is launched eagerly (*graph_replay_enabled = 0).  With
  * CMAX_PLAN_GRAPHS=1 in the environment at plan creation, evaluations after the first few are replayed from
  * captured hipGraphs (one per distinct launch sequence; 0 again if a capture failed).                        */
