@@ -459,3 +459,54 @@ def test_native_plan_value_only_calls_complete_promptly(golden):
         if i % 2 == 0:
             assert abs(lv - l_ref) <= 1e-9 * abs(l_ref)
     assert time.perf_counter() - t0 < 0.5, time.perf_counter() - t0
+
+
+@pytest.mark.parametrize("time_aware", [False, True])
+def test_pyramid_solver_reused_across_frames(time_aware):
+    """One solver instance over consecutive batches (main.py's loop): the handle and the per-scale objectives persist, the
+    batches differ in size, duration and motion.  Every frame must be solved as well as by a fresh solver started from
+    the same random initialisation (how well that is depends on the frame)."""
+    from event_based_optical_flow_amd import solver
+
+    H, W = 68, 90
+    slv_cfg = {"method": "pyramidal_patch_contrast_maximization", "time_aware": time_aware,
+               "patch": {"initialize": "random", "scale": 4, "crop_height": 64, "crop_width": 80, "filter_type": "bilinear"},
+               "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
+               "cost": "hybrid", "outer_padding": 0,
+               "cost_with_weight": {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+               "iwe": {"method": "bilinear_vote", "blur_sigma": 1}}
+    if time_aware:
+        slv_cfg.update({"time_bin": 10, "flow_interpolation": "burgers", "t0_flow_location": "middle"})
+    opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
+               "parameters": {"trans_x": {"min": -30, "max": 30}, "trans_y": {"min": -30, "max": 30}}}
+    make = lambda: solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)  # noqa: E731
+    slv = make()
+    handle_ids, objective_ids = set(), set()
+    for frame, (n, t_scale, amp, seed) in enumerate([(80_000, 0.05, 7.0, 12), (50_000, 0.03, 5.0, 21), (90_000, 0.08, 6.0, 33)]):
+        rng = np.random.default_rng(seed)
+        V = E.utils.generate_smooth_flow((H, W), amp, grid=3, seed=seed)  # pixel displacement over the batch
+        n_dots = 500
+        cx, cy = rng.uniform(4, H - 4, n_dots), rng.uniform(4, W - 4, n_dots)
+        dot = rng.integers(0, n_dots, n)
+        tau = np.sort(rng.uniform(0, 1, n))
+        vx, vy = V[0, cx.astype(int), cy.astype(int)][dot], V[1, cx.astype(int), cy.astype(int)][dot]
+        x = np.clip(np.round(cx[dot] + tau * vx + rng.normal(0, 0.4, n)), 0, H - 1)
+        y = np.clip(np.round(cy[dot] + tau * vy + rng.normal(0, 0.4, n)), 0, W - 1)
+        ev = np.stack([x, y, 3.0 * frame + tau * t_scale, rng.integers(0, 2, n).astype(float)], 1)
+        np.random.seed(46 + frame)
+        best = slv.optimize(ev)
+        np.random.seed(46 + frame)
+        fresh = make()
+        best_fresh = fresh.optimize(ev)
+        handle_ids.add(id(slv._handle))
+        objective_ids.add(tuple(id(slv._objectives[s]) for s in sorted(slv._objectives)))
+        flow = slv.motion_to_dense_flow(best) * t_scale
+        mask = np.zeros((H, W), bool)
+        mask[x.astype(int), y.astype(int)] = True
+        mask[:4] = mask[-4:] = False
+        mask[:, :8] = mask[:, -8:] = False
+        aee = np.sqrt(((flow - V) ** 2).sum(0))[mask].mean()
+        aee_fresh = np.sqrt(((fresh.motion_to_dense_flow(best_fresh) * t_scale - V) ** 2).sum(0))[mask].mean()
+        aee0 = np.sqrt((V ** 2).sum(0))[mask].mean()
+        assert aee < aee0 and aee <= aee_fresh + 0.15 * aee0, (frame, aee, aee_fresh, aee0)
+    assert len(handle_ids) == 1 and len(objective_ids) == 1
