@@ -43,6 +43,7 @@
 
 namespace cmax {
 
+constexpr int kSparseSegment = 512;  // voxel K3: segments below this many events add straight to memory (no LDS accumulators)
 constexpr int kTile = 16;  // source-pixel tile edge of the counting sort
 constexpr int kSegMax = 2040;                 // events per segment (+1 for the even-aligned start still fits 2048);
                                               // |sum of votes| <= 2040 * 2^20 < 2^31
@@ -1356,13 +1357,17 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // window of such a segment (16 * span + displacement range wide) overflowed its 4096 words as soon as the motion
     // was a few pixels, and the clipped path (bounds tests, global atomics for the overflow) made those few workgroups
     // the tail of the launch: 1M events whose lower tile rows are sparse, K1 7.5 -> 6.9 us, K3 10.4 -> 7.3 us.
-    const int max_groups = T == 1 ? 3 : kAccCells / 256;
+    // binned handles: 12 (tile, bin) groups, what the LDS accumulators of the voxel K3 hold -- unless every segment is
+    // below kSparseSegment events anyway (then that kernel adds straight to memory): up to 3 tiles' worth of groups,
+    // instead of ~100-event segments cut by the span (30k events, T = 10: 312 -> 125 segments)
+    int max_groups = T == 1 ? 3 : kAccCells / 256;
     const bool free_cut = h->n > (int64_t)1024 * kSegMax;
     // batches far below one full segment per CU (the solver's 30k-event slices): a workgroup walks its events
     // 8 (4) per thread, so 2040-event segments leave 15 workgroups with long serial work on a 256-CU chip.
     // Cap the segment at n / 512 (>= 256 events): cfg1-shaped K3 13 -> 5 us.
     int seg_cap = kSegMax;
     if (h->n < (int64_t)256 * kSegMax) seg_cap = (int)std::min<int64_t>(kSegMax, std::max<int64_t>(256, (h->n + 511) / 512));
+    if (T > 1 && seg_cap < kSparseSegment) max_groups = std::max(max_groups, 3 * T);
     std::vector<int4> segs;
     int begin = 0, count = 0, row_of_begin = -1, g0 = 0, g_last = 0;
     auto close = [&]() {
