@@ -414,7 +414,6 @@ template <typename T>
 int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T *gV, T *gF, hipStream_t s) {
     const int64_t sz = 2 * (int64_t)H * W;
     const T tau = (T)(1.0 / (double)Tn);
-    const int grid = div_up((int64_t)H * W, 256);
     const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
     for (int j = nstep; j >= 1; --j) {  // j = distance of the step's INPUT bin from t0, outermost first
         StepJobs<T> jobs = {};
@@ -485,7 +484,6 @@ template <typename T>
 int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int W, int scheme, T *gV, T *dgV, T *gF, T *dgF, hipStream_t s) {
     const int64_t sz = 2 * (int64_t)H * W;
     const T tau = (T)(1.0 / (double)Tn);
-    const int grid = div_up((int64_t)H * W, 256);
     const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
     for (int j = nstep; j >= 1; --j) {
         DualJobs<T> jobs = {};

@@ -1129,16 +1129,27 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 #define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, STRIDED) \
     hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, STRIDED>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
-    if constexpr (MODEL == CMAX_MODEL_DENSE) {                                \
-        if (strided) CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, true);                \
-        else CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false);                       \
-    } else CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false)
-#define CMAX_LAUNCH_GRAD_FR(NS, FRAC)                                                  \
-    if (fold == kFoldDeferred) {                                                       \
-        if constexpr (MODEL == CMAX_MODEL_2DOF) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); \
-    } else if (fold == kFoldStats) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);             \
-    else if (fold == kFoldScale) CMAX_LAUNCH_GRAD(NS, FRAC, kFoldScale);               \
-    else CMAX_LAUNCH_GRAD(NS, FRAC, kFoldNone);
+    do {                                                                      \
+        if constexpr (MODEL == CMAX_MODEL_DENSE) {                            \
+            if (strided) {                                                    \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, true);                     \
+            } else {                                                          \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false);                    \
+            }                                                                 \
+        } else {                                                              \
+            CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false);                        \
+        }                                                                     \
+    } while (0)
+#define CMAX_LAUNCH_GRAD_FR(NS, FRAC)                                                        \
+    if (fold == kFoldDeferred) {                                                             \
+        if constexpr (MODEL == CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); } \
+    } else if (fold == kFoldStats) {                                                         \
+        CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);                                              \
+    } else if (fold == kFoldScale) {                                                         \
+        CMAX_LAUNCH_GRAD(NS, FRAC, kFoldScale);                                              \
+    } else {                                                                                 \
+        CMAX_LAUNCH_GRAD(NS, FRAC, kFoldNone);                                               \
+    }
 #define CMAX_LAUNCH_GRAD_NS(NS)          \
     if (h->has_frac) {                   \
         CMAX_LAUNCH_GRAD_FR(NS, true)    \
