@@ -46,7 +46,13 @@ k_accumulate(const float *__restrict__ g, int64_t n, double w, int first, double
 __global__ void __launch_bounds__(256) k_absmax(const double *__restrict__ x, int64_t n, unsigned long long *__restrict__ bits) {
     __shared__ double s_m[256 / kWave];
     double m = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(x[i]));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {  // four independent loads in flight per thread
+        const double a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+        m = fmax(fmax(m, fmax(fabs(a), fabs(b))), fmax(fabs(c), fabs(d)));
+    }
+    for (; i < n; i += stride) m = fmax(m, fabs(x[i]));
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, kWave));
     if ((threadIdx.x & (kWave - 1)) == 0) s_m[threadIdx.x / kWave] = m;
