@@ -454,20 +454,27 @@ int voxel_construct_tan(const T *F, const T *dF, int Tn, int t0, int H, int W, i
     const T tau = (T)(1.0 / (double)Tn);
     const int grid = div_up((int64_t)H * W, 256);
     const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
-    CMAX_CHECK_HIP(hipMemcpyAsync(V + (int64_t)t0 * sz, F, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
-    CMAX_CHECK_HIP(hipMemcpyAsync(dV + (int64_t)t0 * sz, dF, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (nstep == 0) {
+        CMAX_CHECK_HIP(hipMemcpyAsync(V + (int64_t)t0 * sz, F, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+        CMAX_CHECK_HIP(hipMemcpyAsync(dV + (int64_t)t0 * sz, dF, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
     for (int j = 1; j <= nstep; ++j) {
         DualJobs<T> jobs = {};
         int n = 0;
+        // the first steps read (F, dF) directly; bin t0 is filled by a copy job of the same launch
         if (j <= nb) {
             const int64_t a = (int64_t)(t0 - j + 1) * sz, b = (int64_t)(t0 - j) * sz;
-            jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.dst[n] = V + b; jobs.ddst[n] = dV + b;
+            jobs.src[n] = j == 1 ? F : V + a; jobs.dsrc[n] = j == 1 ? dF : dV + a; jobs.dst[n] = V + b; jobs.ddst[n] = dV + b;
             jobs.s[n++] = (T)-1;
         }
         if (j <= nf) {
             const int64_t a = (int64_t)(t0 + j - 1) * sz, b = (int64_t)(t0 + j) * sz;
-            jobs.src[n] = V + a; jobs.dsrc[n] = dV + a; jobs.dst[n] = V + b; jobs.ddst[n] = dV + b;
+            jobs.src[n] = j == 1 ? F : V + a; jobs.dsrc[n] = j == 1 ? dF : dV + a; jobs.dst[n] = V + b; jobs.ddst[n] = dV + b;
             jobs.s[n++] = (T)1;
+        }
+        if (j == 1) {
+            jobs.src[n] = F; jobs.dsrc[n] = dF; jobs.dst[n] = V + (int64_t)t0 * sz; jobs.ddst[n] = dV + (int64_t)t0 * sz;
+            jobs.s[n++] = (T)0;
         }
         if (scheme == CMAX_SCHEME_BURGERS)
             hipLaunchKernelGGL((k_flow_step_dual<T, CMAX_SCHEME_BURGERS>), dim3(grid, n), dim3(256), 0, s, jobs, H, W, tau);
@@ -507,7 +514,7 @@ int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int 
         CMAX_CHECK_LAUNCH();
     }
     if (gF) CMAX_CHECK_HIP(hipMemcpyAsync(gF, gV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
-    CMAX_CHECK_HIP(hipMemcpyAsync(dgF, dgV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (dgF) CMAX_CHECK_HIP(hipMemcpyAsync(dgF, dgV + (int64_t)t0 * sz, sz * sizeof(T), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -577,7 +584,7 @@ int cmax_voxel_construct_tan(const void *F, const void *dF, int dtype, int Tn, i
 
 int cmax_voxel_construct_adj_tan(const void *V, const void *dV, int dtype, int Tn, int t0, int H, int W, int scheme, void *gV, void *dgV,
                                  void *gF, void *dgF, cmax_stream_t stream) {
-    CMAX_REQUIRE(V && dV && gV && dgV && dgF && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj_tan");
+    CMAX_REQUIRE(V && dV && gV && dgV && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj_tan");
     CMAX_REQUIRE(scheme == CMAX_SCHEME_BURGERS || scheme == CMAX_SCHEME_UPWIND, "voxel_construct_adj_tan: scheme");
     if (dtype == CMAX_F32)
         return voxel_construct_adj_tan<float>((const float *)V, (const float *)dV, Tn, t0, H, W, scheme, (float *)gV, (float *)dgV, (float *)gF, (float *)dgF, (hipStream_t)stream);

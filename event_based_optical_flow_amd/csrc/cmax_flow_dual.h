@@ -51,11 +51,11 @@ template <typename T>
 __device__ __forceinline__ Dual<T> d_abs(Dual<T> a) { return Dual<T>(a.v < (T)0 ? -a.v : a.v, d_sgn(a) * a.d); }
 
 template <typename T>
-struct DualJobs {  // up to 2 jobs per launch (blockIdx.y): the two time directions
-    const T *src[2], *dsrc[2];    // V_i, dV_i
-    T *dst[2], *ddst[2];          // forward: V_next, dV_next; adjoint: lambda_i, dlambda_i (accumulated)
-    const T *gout[2], *dgout[2];  // adjoint: lambda_next, dlambda_next
-    T s[2];
+struct DualJobs {  // up to 3 jobs per launch (blockIdx.y): the two time directions (+ the copy of bin t0 in the first forward launch)
+    const T *src[3], *dsrc[3];    // V_i, dV_i
+    T *dst[3], *ddst[3];          // forward: V_next, dV_next; adjoint: lambda_i, dlambda_i (accumulated)
+    const T *gout[3], *dgout[3];  // adjoint: lambda_next, dlambda_next
+    T s[3];                       // +-1: time direction of the step; 0 (forward only): plain copy
 };
 
 // forward step on dual numbers: same formulas as flow_step_pixel (flow_utils.py:582-639 / 459-492)
@@ -68,6 +68,13 @@ __global__ void __launch_bounds__(256) k_flow_step_dual(DualJobs<T> jobs, int H,
     const int64_t hw = (int64_t)H * W;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hw) return;
+    if (s == (T)0) {  // copy job: bin t0 holds (F, dF) themselves
+        jobs.dst[y][p] = F[p];
+        jobs.dst[y][hw + p] = F[hw + p];
+        jobs.ddst[y][p] = dF[p];
+        jobs.ddst[y][hw + p] = dF[hw + p];
+        return;
+    }
     const int i = (int)(p / W), j = (int)(p % W);
     auto U = [&](int r, int c) { return N(s * F[(int64_t)r * W + c], s * dF[(int64_t)r * W + c]); };
     auto V = [&](int r, int c) { return N(s * F[hw + (int64_t)r * W + c], s * dF[hw + (int64_t)r * W + c]); };

@@ -362,9 +362,10 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
         hipLaunchKernelGGL(k_accumulate, dim3(mgrid), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->dgacc64, (const double *)p->scal);
         CMAX_CHECK_LAUNCH();
     }
-    rc = cmax_voxel_construct_adj_tan(p->vox64, p->dvox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->dgacc64, nullptr, p->dgflow64, s);
+    // the sweep leaves d(dL/dF) in bin t0 of the tangent gradient voxel: the interpolation adjoint reads it there
+    rc = cmax_voxel_construct_adj_tan(p->vox64, p->dvox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->dgacc64, nullptr, nullptr, s);
     if (rc) return rc;
-    rc = cmax_patch_to_dense(p->dgflow64, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
+    rc = cmax_patch_to_dense(p->dgacc64 + (int64_t)d.t0 * p->nflow, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
     if (rc) return rc;
     FinalParams fp;
     fp.n_terms = 0;

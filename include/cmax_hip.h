@@ -156,8 +156,9 @@ int cmax_voxel_construct_adj(const void *V, int dtype, int T, int t0, int H, int
 /* Second order of the same chain, for exact Hessian-vector products of time-aware objectives (what
  * torch.autograd.functional.vhp differentiates, src/solver/scipy_autograd/torch_wrapper.py:51-73):
  *   _tan      V[T,2,H,W] and its directional derivative dV along dF, in one sweep
- *   _adj_tan  on entry gV = dL/dV, dgV = its tangent (both clobbered); gF[2,H,W] = dL/dF (NULL: not wanted),
- *             dgF[2,H,W] = d/d(eps) [dL/dF](F + eps dF) = J^T dgV + (dJ[dV])^T gV
+ *   _adj_tan  on entry gV = dL/dV, dgV = its tangent (both clobbered: the sweep leaves the results in their bins
+ *             t0); gF[2,H,W] = copy of dL/dF, dgF[2,H,W] = copy of d/d(eps) [dL/dF](F + eps dF)
+ *             = J^T dgV + (dJ[dV])^T gV   (either may be NULL: no copy)
  * sign(), the selectors of maximum / minimum and |.|' are piecewise constant (torch's convention).          */
 int cmax_voxel_construct_tan(const void *F, const void *dF, int dtype, int T, int t0, int H, int W, int scheme,
                              void *V, void *dV, cmax_stream_t stream);
