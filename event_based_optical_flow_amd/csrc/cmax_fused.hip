@@ -1435,9 +1435,9 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
 }
 
 // Order `n_in` events from `src` for h->n_time_bin (cmax_sort_kernels.h) into the handle's SoA, then build the work
-// list.  d_flags must be prepared by the caller ([1], [2] zero; [0] zero for a new batch).
+// list.  first_flag: d_flags[first_flag .. 3] are cleared (0 for a new batch; 1 keeps "fractional sources" when re-binning).
 template <typename SRC>
-static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool reduce_time, hipStream_t s) {
+static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool reduce_time, int first_flag, hipStream_t s) {
     const int ntiles = h->ntr * h->ntc, T = h->n_time_bin;
     if (h->cap_alt < h->cap) {  // staging SoA of the bucket pass
         CMAX_CHECK_HIP(hipStreamSynchronize(s));
@@ -1452,13 +1452,12 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
         if (rc) return rc;
         h->cap_alt = h->cap;
     }
-    CMAX_CHECK_HIP(hipMemsetAsync(h->counts, 0, (size_t)(ntiles + 1) * sizeof(int), s));
-    CMAX_CHECK_HIP(hipMemsetAsync(h->cursor, 0, (size_t)ntiles * sizeof(int), s));
+
     const int grid = (int)div_up(n_in, (int64_t)kSortChunk);
     const SortOut stage = {h->evp_alt, h->rx_alt, h->ry_alt, h->tau64_alt};
     const SortOut fin = {h->evp, h->rx, h->ry, h->tau64};
     unsigned long long *keys = reduce_time ? reinterpret_cast<unsigned long long *>(h->d_tmm) : nullptr;
-    if (keys) CMAX_CHECK_HIP(hipMemsetAsync(keys, 0, 2 * sizeof(unsigned long long), s));  // "empty" for both atomicMax reductions
+    hipLaunchKernelGGL(k_sort_clear, dim3(div_up(ntiles + 1, 256)), dim3(256), 0, s, h->counts, h->cursor, ntiles, h->d_flags, first_flag, keys);
     hipLaunchKernelGGL((k_bucket_hist<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, h->counts, h->d_flags, keys);
     launch_scan(h, ntiles, s);
     hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, h->d_flags, stage);
@@ -1612,17 +1611,17 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         hipLaunchKernelGGL(k_tmm_set, dim3(1), dim3(1), 0, s, h->d_tmm, (double)INFINITY, -(double)INFINITY);
         CMAX_CHECK_LAUNCH();
     }
-    CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
     h->n_time_bin = n_time_bin;
     if (n == 0) {
+        CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
         h->has_frac = false;
         h->nseg = 0;
         return 0;
     }
     // pack + order (tile-major; by pixel or by time bin inside a tile) + work list; one host synchronisation
     const int keyed = have_tminmax ? 0 : 1;
-    if (dtype == CMAX_F32) return sort_events(h, RawSource<float>{(const float *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, s);
-    return sort_events(h, RawSource<double>{(const double *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, s);
+    if (dtype == CMAX_F32) return sort_events(h, RawSource<float>{(const float *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, 0, s);
+    return sort_events(h, RawSource<double>{(const double *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, 0, s);
 }
 
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
@@ -1634,8 +1633,7 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     if (h->n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // re-order the packed events in place (through the staging SoA); [0] "fractional sources" stays what it was
-    CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(int), s));
-    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, s);
+    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, s);
 }
 
 int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac, int normalize_t,

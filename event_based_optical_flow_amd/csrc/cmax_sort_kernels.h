@@ -135,6 +135,17 @@ struct SortOut {
     double *tau64;
 };
 
+// S0.  Everything the sort accumulates into, cleared by one launch (four hipMemsetAsync nodes cost ~3 us each):
+// tile counts [ntiles + 1], tile cursors [ntiles], flags [first_flag, 4), the keyed time extremes (optional).
+__global__ void __launch_bounds__(256) k_sort_clear(int *__restrict__ tile_count, int *__restrict__ tile_cursor, int ntiles, int *__restrict__ flags,
+                                                    int first_flag, unsigned long long *__restrict__ tmm_keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= ntiles) tile_count[i] = 0;
+    if (i < ntiles) tile_cursor[i] = 0;
+    if (i >= first_flag && i < 4) flags[i] = 0;
+    if (tmm_keys && i < 2) tmm_keys[i] = 0ull;  // "empty" for both atomicMax reductions
+}
+
 // S1.  tile_count[ntiles] += events per tile; flags[0] = any fractional source coordinate, flags[1] += dropped events;
 // tmm_keys (RawSource with keyed extremes): batch time extremes, two atomics per workgroup.
 template <typename SRC>
