@@ -23,7 +23,13 @@ SCHEME_CODES = {"burgers": _lib.SCHEME_BURGERS, "upwind": _lib.SCHEME_UPWIND}
 _DIRECTION_FRAC = {"middle": 0.5, "before": -1.0, "after": 2.0}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device (the stream every library call is enqueued on)."""
+    if _raw_stream is not None:  # one C call instead of building a torch.cuda.Stream object (~3 us per library call)
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
