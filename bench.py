@@ -2,18 +2,24 @@
 """Headline benchmark: events/s through ONE objective evaluation = warp + IWE accumulate + cost +
 analytic gradient (BASELINE.json metric), on synthetic events already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE configs[1] = 1M synthetic events, 346x260 (H=260, W=346),
-2-DoF translational flow, image-variance cost + analytic gradient.  For N > 1 every rank owns one
-1M-event time slice of an N x 1M-event batch (weak scaling), with an RCCL all-reduce of the IWE and
-of the gradient per evaluation (event_based_optical_flow_amd/distributed.py).
+Workload (config.workload): BASELINE configs[1] = cfg2 = 1M synthetic events, 346x260 (H=260, W=346), 2-DoF
+translational flow, image-variance cost + analytic gradient.  For N > 1 every rank owns one 1M-event time slice of an
+N x 1M-event batch (weak scaling); both all-reduces of an evaluation (IWE, gradient) are enqueued by libcmax_hip.so
+itself (RCCL, cmax_objective_dist).  `also` carries the other single-GPU configurations (cfg3, cfg4, a cfg5 shard)
+and, for N > 1, cfg5 = 20M events 1280x720 split into N time slices (strong scaling).
+
+Timing: W warm-up steps, then `windows` (default 25) windows of EXACTLY K steps, each bracketed by barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks per window; ms_per_step / value are the MEDIAN window.
 
 One JSON line on stdout (rank 0).  Extra objects:
-  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration, the duration
-                measured with HIP events on the launch stream in an instrumented pass of the same K
-                steps (cmax_set_profiling); peak = 8.0 TB/s HBM (MI355X_MICROARCH.md)
+  roofline      bound hbm; achieved = SURVEY 8(d) algorithmic bytes of ONE EVALUATION / median step time
+                (frac = achieved / 8 TB/s); `kernels` = the same per kernel class (bytes per launch / mean
+                launch duration, HIP events on the launch stream in an instrumented pass of the same steps,
+                cmax_set_profiling), `dominant` names the longest one
   cpu_baseline  the CPU oracle (oracle/cmax_oracle.c, scalar C, 1 core) timed on this host on the
                 same workload -- a reported baseline, not the target; cpu_baseline_torch: the same evaluation
                 written the way the reference is (torch tensor ops + autograd, oracle/torch_cpu.py) on the
@@ -22,6 +28,8 @@ One JSON line on stdout (rank 0).  Extra objects:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,8 +49,13 @@ WORKLOADS = {
     "cfg4": dict(H=260, W=346, n=2_000_000, model="dense-flow-voxel", cost="image_variance", sigma=1.0,
                  desc="cfg4: 2M synthetic events, 346x260, Burgers voxel T=10 (t0 middle) + voxel warp, image_variance"),
     "cfg5": dict(H=720, W=1280, n=2_500_000, model="dense-flow", cost="image_variance", sigma=0.0,
-                 desc="cfg5: 20M/8 = 2.5M events per GPU, 1280x720, dense flow, image_variance"),
+                 desc="cfg5 shard: 20M/8 = 2.5M events per GPU, 1280x720, dense flow, image_variance"),
+    # cfg5 as BASELINE states it: ONE 20M-event batch, time-sliced over the N ranks (strong scaling)
+    "cfg5_strong": dict(H=720, W=1280, n=20_000_000, model="dense-flow", cost="image_variance", sigma=0.0, strong=True,
+                        desc="cfg5: 20M synthetic events, 1280x720, dense flow, image_variance, time-sliced over the ranks"),
 }
+KERNEL_NAMES = {"vote": "k_vote (K1 warp + bilinear vote)", "grad": "k_grad (K3 gather + gradient)", "stats": "k_stats* (K2 image statistics)",
+                "gimage": "k_gimage* (K2b dL/dIWE)", "finish": "k_finish* (final reduction)", "comm": "RCCL all-reduce"}
 
 
 def algorithmic_bytes(kernel: str, n: int, H: int, W: int, model: str, T: int) -> float:
@@ -53,7 +66,13 @@ def algorithmic_bytes(kernel: str, n: int, H: int, W: int, model: str, T: int) -
     tp = 0 if model == "2d-translation" else (T if model == "dense-flow-voxel" else 1)
     if kernel in ("vote", "grad"):
         return 12.0 * n + 4.0 * H * W + 8.0 * H * W * tp
-    return 4.0 * H * W
+    if kernel in ("stats", "gimage"):
+        return 4.0 * H * W
+    return 0.0
+
+
+def evaluation_bytes(n: int, H: int, W: int, model: str, T: int) -> float:
+    return sum(algorithmic_bytes(k, n, H, W, model, T) for k in ("vote", "stats", "gimage", "grad"))
 
 
 def measured_traffic(workload: str, kernel: str):
@@ -69,13 +88,18 @@ def measured_traffic(workload: str, kernel: str):
     return None
 
 
-def make_inputs(cfg, rank, world, seed=46):
+def make_inputs(cfg, rank, world, seed=46, structured=False):
+    """This rank's time slice [rank, rank + 1) * period / world of the batch (host fp64 [n, 4]) and the motion."""
     import event_based_optical_flow_amd as E
 
-    H, W, n = cfg["H"], cfg["W"], cfg["n"]
+    H, W = cfg["H"], cfg["W"]
+    n = cfg["n"] // world if cfg.get("strong") else cfg["n"]
     period = 0.05
-    # rank r owns the time slice [r, r+1) * period / world of the global batch
-    ev = E.utils.generate_events(n, H, W, tmin=rank * period / world, tmax=(rank + 1) * period / world, seed=seed + rank)
+    t0, t1 = rank * period / world, (rank + 1) * period / world
+    if structured and cfg["model"] == "2d-translation":
+        ev = E.utils.generate_structured_events(n, H, W, (12.3, -7.7), n_dots=2500, tmin=t0, tmax=t1, seed=seed + rank)
+    else:
+        ev = E.utils.generate_events(n, H, W, tmin=t0, tmax=t1, seed=seed + rank)
     T = 0
     if cfg["model"] == "2d-translation":
         motion = np.array([12.3, -7.7])
@@ -83,7 +107,7 @@ def make_inputs(cfg, rank, world, seed=46):
         motion = E.utils.generate_smooth_flow((H, W), 20, seed=seed + 1000)
     else:
         T = 10
-        motion = None  # built on the GPU below from the t0 flow
+        motion = None  # built on the GPU from the t0 flow
     return ev, motion, T
 
 
@@ -131,54 +155,21 @@ def cpu_baseline_torch(cfg, ev, motion, budget_s=8.0):
             "host_cpus": os.cpu_count()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--events", default="uniform", choices=["uniform", "structured"])
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 path on a 1-GPU box)")
-    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (1-GPU box testing with --backend gloo)")
-    args = ap.parse_args()
-
+def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=True, keep_inputs=False):
+    """Sets the workload up on this rank, times `windows` windows of `steps` evaluations, optionally profiles the kernel
+    classes.  Returns a dict (rank 0 uses it; every rank must call this: the timing holds collectives)."""
     import torch
     import torch.distributed as dist
 
     import event_based_optical_flow_amd as E
     from event_based_optical_flow_amd.distributed import TimeSlicedObjective
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.share_gpu:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo")
-    elif args.gpus != 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-
-    cfg = WORKLOADS[args.workload]
-    H, W, n = cfg["H"], cfg["W"], cfg["n"]
-    ev, motion, T = make_inputs(cfg, rank, world)
-    if args.events == "structured" and cfg["model"] == "2d-translation":
-        ev = E.utils.generate_structured_events(n, H, W, (12.3, -7.7), n_dots=2500, tmin=rank * 0.05 / world,
-                                                tmax=(rank + 1) * 0.05 / world, seed=46 + rank)
-
+    cfg = WORKLOADS[name]
+    H, W = cfg["H"], cfg["W"]
+    ev, motion, T = make_inputs(cfg, rank, world, structured=args.events == "structured")
+    n_local = ev.shape[0]
     handle = E.CMaxHandle((H, W))
-    sliced = TimeSlicedObjective(handle)
+    sliced = TimeSlicedObjective(handle, in_library=not args.torch_collectives)
     ev_dev = torch.from_numpy(ev).to(dev)  # fp64 [n,4] resident in HBM before anything is timed
     sliced.set_local_events(ev_dev, time_bin=T, device=dev)  # first call: workspace allocation, code-object load
     torch.cuda.synchronize()
@@ -186,6 +177,7 @@ def main():
     sliced.set_local_events(ev_dev, time_bin=T, device=dev)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t0) * 1e3  # once per batch: pack + counting sort + work list (not in `value`)
+    del ev_dev
 
     if cfg["model"] == "dense-flow-voxel":
         f0 = torch.from_numpy(E.utils.generate_smooth_flow((H, W), 20, seed=1046)).to(dev)
@@ -203,85 +195,212 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         res, grad = step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, grad = step()
-    torch.cuda.synchronize()
+    times = []
+    for _ in range(windows):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res, grad = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        times.append(time.perf_counter() - t0)
+    times = torch.tensor(times, dtype=torch.float64, device=dev)
     if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)  # a window lasts as long as its slowest rank
+    times = np.sort(times.cpu().numpy())
+    elapsed = float(np.median(times))
     loss = float(res[0].item())
+    n_total = n_local * world
 
-    # instrumented passes (after the timed region, same inputs): HIP events recorded on the launch stream
-    # around every launch of the four hot kernel classes.
-    #  (a) one launch per bracket: what an evaluation actually runs, but each bracket adds ~2.5 us of
-    #      marker / dispatch latency to kernels that only run ~8 us;
-    #  (b) REPEAT launches per bracket: amortises that latency -> the per-launch duration used for the
-    #      roofline (agrees with the rocprofv3 kernel durations under profiles/).
-    REPEAT = 8
-    handle.set_profiling(True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    prof_single = handle.read_profile()
-    handle.set_profiling(True, repeat=REPEAT)
-    for _ in range(max(args.steps // 4, 10)):
-        step()
-    torch.cuda.synchronize()
-    prof = handle.read_profile()
-    handle.set_profiling(False)
+    out = {"workload": cfg["desc"], "events_per_gpu": n_local, "events_total": n_total, "image": [H, W], "motion_model": cfg["model"],
+           "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "time_bins": T,
+           "ms_per_step": elapsed / steps * 1e3, "value": n_total * steps / elapsed,
+           "window_ms_per_step": {"min": float(times[0]) / steps * 1e3, "median": elapsed / steps * 1e3, "max": float(times[-1]) / steps * 1e3,
+                                  "windows": windows, "steps_per_window": steps},
+           "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives}
+    if world > 1:
+        out["rccl"] = dict(zip(("nranks", "rank", "version"), handle.comm_info()))
+    # B / t_eval.  Per GPU: N/g events + the full images (every rank evaluates the image-space part)
+    eval_bytes = evaluation_bytes(n_local, H, W, cfg["model"], T)
+    out["evaluation_bytes_per_gpu"] = eval_bytes
+    out["evaluation_GBps_per_gpu"] = eval_bytes / (out["ms_per_step"] * 1e-3) / 1e9
+    out["evaluation_frac"] = out["evaluation_GBps_per_gpu"] / HBM_PEAK_GBS
+
+    if profile:
+        # instrumented passes (after the timed region, same inputs): HIP events recorded on the launch stream
+        # around every launch of the kernel classes.
+        #  (a) one launch per bracket: what an evaluation actually runs, but each bracket adds ~2.5 us of
+        #      marker / dispatch latency to kernels that only run ~8 us;
+        #  (b) REPEAT launches per bracket: amortises that latency -> the per-launch duration used for the
+        #      per-kernel roofline (agrees with the rocprofv3 kernel durations under profiles/).
+        REPEAT = 8
+        psteps = min(steps, 100)
+        handle.set_profiling(True)
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        prof_single = handle.read_profile()
+        handle.set_profiling(True, repeat=REPEAT)
+        for _ in range(max(psteps // 4, 10)):
+            step()
+        torch.cuda.synchronize()
+        prof = handle.read_profile()
+        handle.set_profiling(False)
+        hot = ("vote", "stats", "gimage", "grad")
+        per_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof.items()}  # us per launch
+        single = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof_single.items()}
+        kernels = {}
+        for k in hot:
+            if per_kernel[k] <= 0:
+                continue
+            ab = algorithmic_bytes(k, n_local, H, W, cfg["model"], T)
+            gbps = ab / (per_kernel[k] * 1e-6) / 1e9
+            kernels[k] = {"kernel": KERNEL_NAMES[k], "launch_us": per_kernel[k], "single_launch_bracket_us": single[k],
+                          "algorithmic_bytes_per_launch": ab, "GBps": gbps, "frac": gbps / HBM_PEAK_GBS,
+                          "traffic": measured_traffic(name, k)}
+        for k in ("finish", "comm"):  # never repeated inside a bracket: the single-launch figure is the only one
+            if single.get(k, 0.0) > 0:
+                kernels[k] = {"kernel": KERNEL_NAMES[k], "single_launch_bracket_us": single[k],
+                              "launches_per_evaluation": prof_single[k][1] / psteps}
+        out["kernels"] = kernels
+        out["dominant"] = max((k for k in hot if k in kernels), key=lambda k: kernels[k]["launch_us"])
+        out["profile_method"] = ("HIP events on the launch stream; each bracket of a hot class holds %d back-to-back launches of the "
+                                 "kernel (instrumented pass after the timed region, same inputs)" % REPEAT)
+    if keep_inputs:
+        out["_inputs"] = (cfg, ev, motion)
+    handle.close()
+    return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks ourselves."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.share_gpu:
+        raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=25, help="timed windows of --steps evaluations; the median window is reported")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other configurations (cfg3, cfg4, cfg5) reported under `also`")
+    ap.add_argument("--events", default="uniform", choices=["uniform", "structured"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="N > 1: all-reduce with torch.distributed around the phase-split calls instead of inside the library")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (1-GPU box testing with --backend gloo)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.share_gpu:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    main_res = run_workload(args.workload, args, rank, world, dev, args.steps, args.warmup, args.windows, keep_inputs=True)
+    cfg, ev, motion = main_res.pop("_inputs")
+
+    also = {}
+    if not args.no_also:
+        # the other configurations, fewer steps (their evaluations are 2-10x longer); same timing protocol
+        names = [w for w in ("cfg3", "cfg4", "cfg5") if w != args.workload] if world == 1 else ["cfg5_strong"]
+        for wname in names:
+            r = run_workload(wname, args, rank, world, dev, max(10, args.steps // 4), max(3, args.warmup // 4), max(5, args.windows // 2))
+            dom = r.get("dominant")
+            also[wname] = {"workload": r["workload"], "events_total": r["events_total"], "events_per_gpu": r["events_per_gpu"],
+                           "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "events/s",
+                           "scaling": "strong" if WORKLOADS[wname].get("strong") else "weak",
+                           "evaluation_frac": r["evaluation_frac"], "evaluation_GBps_per_gpu": r["evaluation_GBps_per_gpu"],
+                           "dominant_kernel": r["kernels"][dom]["kernel"] if dom else None,
+                           "dominant_kernel_us": r["kernels"][dom]["launch_us"] if dom else None,
+                           "dominant_kernel_frac": r["kernels"][dom]["frac"] if dom else None,
+                           "kernels_us": {k: v.get("launch_us", v.get("single_launch_bracket_us")) for k, v in r.get("kernels", {}).items()},
+                           "collectives": r["collectives"], "prepare_ms_once_per_batch": r["prepare_ms_once_per_batch"]}
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n * world * args.steps / elapsed
-        per_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof.items()}  # us per launch
-        single_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof_single.items()}
-        dominant = max(per_kernel, key=lambda k: per_kernel[k])
-        ab = algorithmic_bytes(dominant, n, H, W, cfg["model"], T)
-        achieved = ab / (per_kernel[dominant] * 1e-6) / 1e9 if per_kernel[dominant] > 0 else 0.0
-        eval_bytes = sum(algorithmic_bytes(k, n, H, W, cfg["model"], T) for k in ("vote", "stats", "gimage", "grad"))
+        H, W, n = cfg["H"], cfg["W"], main_res["events_per_gpu"]
+        dom = main_res["dominant"]
+        kd = main_res["kernels"][dom]
         out = {
             "metric": "events/sec through warp+IWE+cost+grad (one objective evaluation)",
-            "value": value,
+            "value": main_res["value"],
             "unit": "events/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cfg.get("strong") else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (%s events, seed 46)" % args.events,
             "config": {"workload": cfg["desc"], "events_per_gpu": n, "image": [H, W], "motion_model": cfg["model"],
                        "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}",
-                       "collectives": None if world == 1 else f"{args.backend}: all-reduce(IWE) + all-reduce(grad) per evaluation"},
-            "roofline": {"bound": "hbm", "kernel": {"vote": "k_vote (K1 warp + bilinear vote)", "grad": "k_grad (K3 gather + gradient)",
-                                                    "stats": "k_stats (K2)", "gimage": "k_gimage (K2b)"}[dominant],
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.workload, dominant), "algorithmic_bytes_per_launch": ab,
-                         "launch_us": per_kernel[dominant],
-                         "method": "HIP events on the launch stream; each bracket holds %d back-to-back launches of the kernel "
-                                   "(instrumented pass after the timed region, same inputs)" % REPEAT,
-                         "all_kernels_us": per_kernel, "all_kernels_single_launch_bracket_us": single_kernel,
-                         "evaluation_GBps": eval_bytes / (ms_per_step * 1e-3) / 1e9,
-                         "evaluation_frac": eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "loss": loss,
-            "prepare_ms_once_per_batch": prepare_ms,
+                       "collectives": None if world == 1 else main_res["collectives"] + ": all-reduce(IWE) + all-reduce(grad) per evaluation",
+                       "rccl": main_res.get("rccl")},
+            "timing": dict(main_res["window_ms_per_step"], statistic="median window; every window = `steps` evaluations between barrier + "
+                                                                      "synchronize on both sides, max over ranks"),
+            "roofline": {"bound": "hbm",
+                         "scope": "one evaluation (SURVEY 8d: B = 24 N + 16 HW + B_model algorithmic bytes / median step time), per GPU",
+                         "achieved": main_res["evaluation_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": main_res["evaluation_frac"],
+                         "algorithmic_bytes_per_evaluation": main_res["evaluation_bytes_per_gpu"],
+                         "traffic": sum(v for v in (measured_traffic(args.workload, k) for k in ("vote", "stats", "gimage", "grad", "finish")) if v) or None,
+                         "dominant": {"kernel": kd["kernel"], "achieved": kd["GBps"], "frac": kd["frac"], "launch_us": kd["launch_us"],
+                                      "algorithmic_bytes_per_launch": kd["algorithmic_bytes_per_launch"], "traffic": kd["traffic"]},
+                         "kernels": main_res["kernels"], "method": main_res["profile_method"]},
+            "loss": main_res["loss"],
+            "prepare_ms_once_per_batch": main_res["prepare_ms_once_per_batch"],
         }
+        if also:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ev, motion)
             tc = cpu_baseline_torch(cfg, ev, motion)
             if tc is not None:
                 out["cpu_baseline_torch"] = tc
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -75,7 +75,10 @@ MODEL_2DOF, MODEL_DENSE, MODEL_VOXEL = 0, 1, 2
 REF_FIRST, REF_LAST, REF_FRAC = 0, 1, 2
 COST_VARIANCE, COST_GRADMAG = 0, 1
 SCHEME_BURGERS, SCHEME_UPWIND = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
+PROF_CLASSES = 6
+ECOMM = -5
 
 # every symbol include/cmax_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -108,6 +111,13 @@ SIGNATURES = {
     "cmax_objective_hvp": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_vote": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "cmax_comm_unique_id": (c_int, [c_vp]),
+    "cmax_comm_init": (c_int, [c_vp, c_vp, c_int, c_int]),
+    "cmax_comm_destroy": (c_int, [c_vp]),
+    "cmax_comm_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "cmax_comm_allreduce": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "cmax_objective_dist": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
+    "cmax_read_profile_all": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "cmax_sizeof_objective": (c_int, []),
     "cmax_set_profiling": (c_int, [c_vp, c_int]),
     "cmax_read_profile": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),

@@ -201,6 +201,69 @@ class CMaxHandle:
                                               grad.data_ptr() if grad is not None else None, F._stream()))
         return result, grad
 
+    # -- in-library collectives (RCCL over xGMI, see distributed.py) -------------------------------------
+    def comm_init(self, group=None, force_rccl: bool = False):
+        """Give this handle an RCCL communicator over the ranks of the torch.distributed `group` (default: the
+        world): rank 0 draws the rendezvous id (cmax_comm_unique_id), torch.distributed ships it, every rank
+        calls cmax_comm_init.  After that `evaluate_dist` needs no torch.distributed call at all.
+        World size 1: no communicator (evaluate_dist == evaluate) unless force_rccl, which makes a real
+        1-rank communicator so that the N > 1 enqueue sequence can be exercised on one GPU."""
+        import torch.distributed as dist
+
+        have = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size(group) if have else 1
+        rank = dist.get_rank(group) if have else 0
+        if world == 1 and not force_rccl:
+            check(self._lib.cmax_comm_init(self._h, None, 1, 0))
+            return self
+        ids, err = [None], None
+        if rank == 0:
+            buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+            try:
+                check(self._lib.cmax_comm_unique_id(buf))
+                ids = [buf.raw]
+            except _lib.CmaxError as e:  # the other ranks wait in the broadcast below: tell them before raising
+                err = e
+        if world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(ids, src=src, group=group)
+        if ids[0] is None:
+            raise err if err is not None else _lib.CmaxError(_lib.ECOMM, "rank 0 could not draw an RCCL rendezvous id")
+        with torch.cuda.device(self.device):
+            check(self._lib.cmax_comm_init(self._h, ids[0], world, rank))
+        return self
+
+    def comm_info(self) -> Tuple[int, int, int]:
+        """(nranks, rank, RCCL version) of the handle's communicator; (1, 0, 0) without one."""
+        n, r, v = ctypes.c_int(1), ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.cmax_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v)))
+        return n.value, r.value, v.value
+
+    def comm_destroy(self):
+        check(self._lib.cmax_comm_destroy(self._h))
+
+    def comm_allreduce(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+        """In-place all-reduce of a contiguous fp32 / fp64 device tensor on the handle's communicator."""
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("comm_allreduce needs a contiguous device tensor")
+        check(self._lib.cmax_comm_allreduce(self._h, t.data_ptr(), t.numel(), F._code(t), {"sum": 0, "min": 1, "max": 2}[op], F._stream()))
+        return t
+
+    def evaluate_dist(self, desc: CmaxObjective, motion, want_grad: bool = True):
+        """One cmax_objective_dist call: the evaluation of the whole time-sliced batch, both all-reduces enqueued
+        by the library between its kernels.  Same returns as `evaluate`, the same on every rank."""
+        m = self._motion32(motion)
+        result = torch.empty(8, dtype=torch.float64, device=self.device)
+        grad = None
+        if want_grad:
+            if desc.model == _lib.MODEL_2DOF:
+                grad = torch.empty(2, dtype=torch.float64, device=self.device)
+            else:
+                grad = torch.empty(tuple(m.shape), dtype=torch.float32, device=self.device)
+        check(self._lib.cmax_objective_dist(self._h, ctypes.byref(desc), m.data_ptr(), result.data_ptr(),
+                                            grad.data_ptr() if grad is not None else None, F._stream()))
+        return result, grad
+
     # -- per-patch translation search (pyramid re-initialisation) ----------------------------------------
     def patch_search(self, boxes, patch_image_size: Tuple[int, int], candidates, sigma: float = 1.0):
         """Score translation candidates per patch with the reference's small-patch cost
@@ -228,11 +291,12 @@ class CMaxHandle:
         check(self._lib.cmax_set_profiling(self._h, (int(repeat) if repeat > 1 else 1) if enable else 0))
 
     def read_profile(self) -> Dict[str, Tuple[float, int]]:
-        """{kernel class: (total ms, launches)} measured with HIP events on the launch stream."""
-        ms = (ctypes.c_double * 4)()
-        cnt = (ctypes.c_int64 * 4)()
-        check(self._lib.cmax_read_profile(self._h, ms, cnt))
-        names = ("vote", "stats", "gimage", "grad")
+        """{kernel class: (total ms, launches)} measured with HIP events on the launch stream: the four hot
+        classes, "finish" (k_finish* / k_finalize) and "comm" (RCCL collectives)."""
+        ms = (ctypes.c_double * _lib.PROF_CLASSES)()
+        cnt = (ctypes.c_int64 * _lib.PROF_CLASSES)()
+        check(self._lib.cmax_read_profile_all(self._h, ms, cnt))
+        names = ("vote", "stats", "gimage", "grad", "finish", "comm")
         return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 
     def last_iwe(self, k: int = 0) -> torch.Tensor:

@@ -36,6 +36,7 @@
 #include <cstring>
 #include <vector>
 
+#include "cmax_comm.h"
 #include "cmax_common.h"
 #include "cmax_image_kernels.h"
 #include "cmax_search_kernels.h"
@@ -158,13 +159,16 @@ struct cmax_handle_s {
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
     bool profiling = false;
     int prof_repeat = 1;  // > 1: every hot launch is issued this many times inside its event bracket (timing only)
-    std::vector<hipEvent_t> prof_ev[4];  // class -> [start0, stop0, start1, stop1, ...]
+    std::vector<hipEvent_t> prof_ev[CMAX_PROF_CLASSES];  // class -> [start0, stop0, start1, stop1, ...]
+    // time-sliced multi-GPU evaluation: this rank's RCCL communicator (cmax_comm_init), or null
+    cmax::Comm *comm = nullptr;
 };
 
 namespace cmax {
 
 // kernel classes for cmax_set_profiling / cmax_read_profile
-enum { kProfVote = 0, kProfStats = 1, kProfGimage = 2, kProfGrad = 3 };
+enum { kProfVote = 0, kProfStats = 1, kProfGimage = 2, kProfGrad = 3, kProfFinish = 4, kProfComm = 5 };
+static_assert(kProfComm + 1 == CMAX_PROF_CLASSES, "profile classes");
 constexpr size_t kProfMaxPairs = 16384;
 
 // RAII: records a HIP event on the launch stream before and after the enclosed launch
@@ -1539,6 +1543,8 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
 
 int cmax_destroy(cmax_handle_t h) {
     if (!h) return 0;
+    comm_destroy(h->comm);
+    h->comm = nullptr;
     dev_free(&h->imgs);
     for (int k = 0; k < 5; ++k) dev_free(&h->iweb[k]);
     dev_free(&h->G);
@@ -1567,7 +1573,7 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->rx_alt);
     dev_free(&h->ry_alt);
     dev_free(&h->tau64_alt);
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CMAX_PROF_CLASSES; ++c)
         for (hipEvent_t e : h->prof_ev[c]) (void)hipEventDestroy(e);
     delete h;
     return 0;
@@ -1695,8 +1701,11 @@ int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float 
 }
 
 // zero_next: base of the image buffer of the NEXT evaluation (k_stats of image k zeroes zero_next[k]) or nullptr
+// reuse_windows: the caller guarantees that `motion` still holds the values of the vote that published h->d_win
+// (cmax_objective / cmax_objective_dist: same call).  The stand-alone cmax_objective_finish cannot know -- a caching
+// allocator hands the same address to a different motion -- and lets K3 derive its windows again.
 static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
-                            float *zero_next, double *result, void *grad, hipStream_t s) {
+                            float *zero_next, double *result, void *grad, hipStream_t s, bool reuse_windows) {
     int rc = 0;
     const int Hp = h->Hp, Wp = h->Wp;
     const int64_t npix = (int64_t)Hp * Wp;
@@ -1777,6 +1786,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         }
     }
     if (!grad || h->n == 0) {  // value only (or a rank without events): the loss needs its own tiny launch
+        ProfScope prof(h, kProfFinish, s);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, op, h->d_stat, result);
         CMAX_CHECK_LAUNCH();
     }
@@ -1810,8 +1820,8 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // ---- per-event gather, all reference times in one launch
     RefArgs ra = {};
     ra.k0 = 0;
-    bool same_vote = h->win_generation == h->generation && h->win_motion == motion && h->win_model == d->model && h->win_nref == d->n_ref &&
-                     h->win_T == d->T && h->win_normalize == d->normalize_t;
+    bool same_vote = reuse_windows && h->win_generation == h->generation && h->win_motion == motion && h->win_model == d->model &&
+                     h->win_nref == d->n_ref && h->win_T == d->T && h->win_normalize == d->normalize_t;
     for (int k = 0; k < d->n_ref; ++k) {
         ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
         ra.img[k] = (fold == kFoldNone || fold == kFoldScale) ? h->G + k * npix : const_cast<float *>(h->last_iwe[k]);
@@ -1829,9 +1839,11 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
     CMAX_CHECK_LAUNCH();
     if (deferred) {
+        ProfScope prof(h, kProfFinish, s);
         hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_gpart, h->nseg, result, (double *)grad);
         CMAX_CHECK_LAUNCH();
     } else if (two_dof) {
+        ProfScope prof(h, kProfFinish, s);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)grad);
         CMAX_CHECK_LAUNCH();
     }
@@ -1844,7 +1856,44 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const floa
     if (rc) return rc;
     CMAX_REQUIRE(images && result, "objective_finish: images / result");
     CMAX_REQUIRE(n_images == d->n_ref || n_images == d->n_ref + 1, "objective_finish: n_images");
-    return objective_finish(h, d, motion, images, n_images, nullptr, result, grad, (hipStream_t)stream);
+    return objective_finish(h, d, motion, images, n_images, nullptr, result, grad, (hipStream_t)stream, false);
+}
+
+// vote -> [all-reduce of the images] -> finish -> [all-reduce of the gradient], all on the handle's double-buffered images
+static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s,
+                          cmax::Comm *comm) {
+    const bool dist = comm != nullptr;  // also a 1-rank communicator: the same enqueue sequence, RCCL included
+    const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
+    const size_t gbytes = d->model == CMAX_MODEL_2DOF ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
+    // empty batch: loss 0, zero gradient (patch_contrast_base.py:253-255).  A time slice may be empty while the batch is not.
+    if (h->n == 0 && !dist) {
+        CMAX_CHECK_HIP(hipMemsetAsync(result, 0, 8 * sizeof(double), s));
+        if (grad) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+        return 0;
+    }
+    const int64_t npix = (int64_t)h->Hp * h->Wp;
+    float *cur = h->imgs + (int64_t)h->cur_buf * 5 * npix;
+    float *nxt = h->imgs + (int64_t)(h->cur_buf ^ 1) * 5 * npix;
+    int n_images = 0;
+    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s);
+    if (rc) return rc;
+    const unsigned used = (1u << n_images) - 1u;
+    h->zero_mask[h->cur_buf] &= ~used;  // now holds votes
+    if (dist) {  // C1: every reference time (+ the un-warped image) in one call; the images are contiguous
+        ProfScope prof(h, kProfComm, s);
+        rc = comm_allreduce(comm, cur, (size_t)n_images * npix, kCommF32, kCommSum, s);
+        if (rc) return rc;
+    }
+    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true);
+    if (rc) return rc;
+    h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
+    h->cur_buf ^= 1;
+    if (dist && grad) {  // C2
+        ProfScope prof(h, kProfComm, s);
+        rc = comm_allreduce(comm, grad, (size_t)gcount, d->model == CMAX_MODEL_2DOF ? kCommF64 : kCommF32, kCommSum, s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad,
@@ -1852,29 +1901,62 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *moti
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(result, "objective: result");
-    // empty batch: loss 0, zero gradient (patch_contrast_base.py:253-255)
-    if (h->n == 0) {
-        hipStream_t s = (hipStream_t)stream;
-        const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
-        const size_t gbytes = d->model == CMAX_MODEL_2DOF ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
-        CMAX_CHECK_HIP(hipMemsetAsync(result, 0, 8 * sizeof(double), s));
-        if (grad) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
-        return 0;
+    return objective_eval(h, d, motion, result, grad, (hipStream_t)stream, nullptr);
+}
+
+int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad,
+                        cmax_stream_t stream) {
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(result, "objective_dist: result");
+    return objective_eval(h, d, motion, result, grad, (hipStream_t)stream, h->comm);
+}
+
+int cmax_comm_unique_id(void *id_host) {
+    CMAX_REQUIRE(id_host != nullptr, "comm_unique_id: id_host");
+    return comm_unique_id(id_host);
+}
+
+int cmax_comm_init(cmax_handle_t h, const void *id_host, int nranks, int rank) {
+    CMAX_REQUIRE(h != nullptr, "comm_init: handle");
+    CMAX_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: need 0 <= rank < nranks");
+    if (h->comm) {
+        comm_destroy(h->comm);
+        h->comm = nullptr;
     }
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t npix = (int64_t)h->Hp * h->Wp;
-    float *cur = h->imgs + (int64_t)h->cur_buf * 5 * npix;
-    float *nxt = h->imgs + (int64_t)(h->cur_buf ^ 1) * 5 * npix;
-    int n_images = 0;
-    rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s);
-    if (rc) return rc;
-    const unsigned used = (1u << n_images) - 1u;
-    h->zero_mask[h->cur_buf] &= ~used;  // now holds votes
-    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s);
-    if (rc) return rc;
-    h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
-    h->cur_buf ^= 1;
+    if (nranks == 1 && !id_host) return 0;  // a single slice is the whole batch: no communicator, RCCL is never loaded
+    CMAX_REQUIRE(id_host != nullptr, "comm_init: id_host");
+    int dev = -1;
+    CMAX_CHECK_HIP(hipGetDevice(&dev));
+    if (dev != h->device) {
+        set_error("comm_init: the current HIP device is %d but the handle lives on device %d", dev, h->device);
+        return CMAX_ESTATE;
+    }
+    return comm_create(id_host, nranks, rank, &h->comm);
+}
+
+int cmax_comm_destroy(cmax_handle_t h) {
+    CMAX_REQUIRE(h != nullptr, "comm_destroy: handle");
+    comm_destroy(h->comm);
+    h->comm = nullptr;
     return 0;
+}
+
+int cmax_comm_info(cmax_handle_t h, int *nranks, int *rank, int *rccl_version) {
+    CMAX_REQUIRE(h != nullptr, "comm_info: handle");
+    if (nranks) *nranks = comm_nranks(h->comm);
+    if (rank) *rank = comm_rank(h->comm);
+    if (rccl_version) *rccl_version = h->comm ? comm_version() : 0;
+    return 0;
+}
+
+int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, int op, cmax_stream_t stream) {
+    CMAX_REQUIRE(h != nullptr && (buf != nullptr || count == 0) && count >= 0, "comm_allreduce: handle / buffer");
+    CMAX_REQUIRE(dtype == CMAX_F32 || dtype == CMAX_F64, "comm_allreduce: dtype");
+    CMAX_REQUIRE(op >= 0 && op <= 2, "comm_allreduce: op must be 0 (sum), 1 (min) or 2 (max)");
+    ProfScope prof(h, kProfComm, (hipStream_t)stream);
+    return comm_allreduce(h->comm, buf, (size_t)count, dtype == CMAX_F64 ? kCommF64 : kCommF32,
+                          op == 1 ? kCommMin : (op == 2 ? kCommMax : kCommSum), (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -2041,7 +2123,7 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *
 int cmax_sizeof_objective(void) { return (int)sizeof(cmax_objective_t); }
 
 static void prof_clear(cmax_handle_s *h) {
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CMAX_PROF_CLASSES; ++c) {
         for (hipEvent_t e : h->prof_ev[c]) (void)hipEventDestroy(e);
         h->prof_ev[c].clear();
     }
@@ -2056,9 +2138,9 @@ int cmax_set_profiling(cmax_handle_t h, int enable) {
     return 0;
 }
 
-int cmax_read_profile(cmax_handle_t h, double *total_ms_host, int64_t *count_host) {
+int cmax_read_profile_all(cmax_handle_t h, double *total_ms_host, int64_t *count_host) {
     CMAX_REQUIRE(h && total_ms_host && count_host, "read_profile");
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CMAX_PROF_CLASSES; ++c) {
         double tot = 0.0;
         const size_t np = h->prof_ev[c].size() / 2;
         for (size_t i = 0; i < np; ++i) {
@@ -2068,9 +2150,22 @@ int cmax_read_profile(cmax_handle_t h, double *total_ms_host, int64_t *count_hos
             tot += (double)ms;
         }
         total_ms_host[c] = tot;
-        count_host[c] = (int64_t)np * h->prof_repeat;
+        count_host[c] = (int64_t)np * (c <= kProfGrad ? h->prof_repeat : 1);  // only the four hot classes are repeated
     }
     prof_clear(h);
+    return 0;
+}
+
+int cmax_read_profile(cmax_handle_t h, double *total_ms_host, int64_t *count_host) {
+    CMAX_REQUIRE(h && total_ms_host && count_host, "read_profile");
+    double ms[CMAX_PROF_CLASSES];
+    int64_t cnt[CMAX_PROF_CLASSES];
+    const int rc = cmax_read_profile_all(h, ms, cnt);
+    if (rc) return rc;
+    for (int c = 0; c < 4; ++c) {
+        total_ms_host[c] = ms[c];
+        count_host[c] = cnt[c];
+    }
     return 0;
 }
 

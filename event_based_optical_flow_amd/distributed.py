@@ -9,7 +9,12 @@ dL/dIWE.  Per objective evaluation there are exactly two exchange steps:
     C2  all-reduce(sum) of the gradient          double[2] | fp32 [2,H,W] | fp32 [T,2,H,W]
 
 Between them every rank redundantly evaluates the (image-space, microseconds) contrast on the
-reduced image, which avoids a broadcast.  t_min / t_max are agreed once per batch with one MIN
+reduced image, which avoids a broadcast.  Both collectives are enqueued BY THE LIBRARY, on the stream
+of its kernels (cmax_comm_init + cmax_objective_dist: RCCL bound inside libcmax_hip.so): one ctypes
+call per evaluation, no Python between the phases.  torch.distributed only ships the RCCL rendezvous
+id once; if the library cannot bring up its communicator (no librccl), or for a `local` without one
+(the CPU test's stand-in), the same two exchange steps run as torch.distributed all-reduces around
+the phase-split calls.  t_min / t_max are agreed once per batch with one MIN
 all-reduce over (t_min, -t_max) because dt normalisation and the voxel bin edges are defined on the whole batch
 (src/warp.py:216-224, 254-259, 342-345).
 
@@ -50,9 +55,26 @@ class TimeSlicedObjective:
         objective_finish(desc, motion, images, want_grad) -> (result[8], grad)
     (CMaxHandle implements it.)"""
 
-    def __init__(self, local, group=None):
+    def __init__(self, local, group=None, in_library: bool = True):
         self.local = local
         self.group = group
+        self.collectives = "none" if self.world_size == 1 else "torch.distributed"
+        if in_library and self.world_size > 1 and hasattr(local, "comm_init") and dist.get_backend(group) == "nccl":
+            # every rank must take the same branch: agree on success before trusting the communicator
+            ok = 1
+            try:
+                local.comm_init(group)
+            except Exception as e:  # RCCL not loadable / communicator refused: the torch path is the same RCCL underneath
+                import warnings
+
+                warnings.warn(f"in-library RCCL communicator unavailable ({e}); using torch.distributed all-reduces")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=getattr(local, "device", "cpu"))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 1:
+                self.collectives = "in-library RCCL (cmax_objective_dist)"
+            elif ok:
+                local.comm_destroy()
 
     @property
     def world_size(self) -> int:
@@ -82,6 +104,8 @@ class TimeSlicedObjective:
     def evaluate(self, desc, motion, want_grad: bool = True):
         if self.world_size == 1 and hasattr(self.local, "evaluate"):
             return self.local.evaluate(desc, motion, want_grad)  # no exchange step: one cmax_objective call
+        if self.collectives.startswith("in-library"):
+            return self.local.evaluate_dist(desc, motion, want_grad)  # vote, C1, finish, C2 enqueued by one library call
         images = self.local.objective_vote(desc, motion)
         self._all_reduce(images)  # C1
         result, grad = self.local.objective_finish(desc, motion, images, want_grad)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CMAX_ABI_VERSION 1
+#define CMAX_ABI_VERSION 2
 
 /* dtypes */
 #define CMAX_F32 0
@@ -57,7 +57,8 @@ extern "C" {
 #define CMAX_EINVAL -1   /* bad argument */
 #define CMAX_ENOMEM -2   /* workspace allocation failed */
 #define CMAX_ESTATE -3   /* call order (e.g. objective before set_events) */
-#define CMAX_ENODEV -4   /* no usable gfx950 device */
+#define CMAX_ENODEV -4   /* no usable gfx950 device / RCCL not loadable */
+#define CMAX_ECOMM -5    /* an RCCL call failed (message in cmax_last_error) */
 
 typedef void *cmax_stream_t; /* hipStream_t */
 typedef struct cmax_handle_s *cmax_handle_t;
@@ -258,6 +259,40 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, co
                           const float *images, int n_images, double *result, void *grad,
                           cmax_stream_t stream);
 
+/* =============================================================================================
+ * Time-sliced multi-GPU evaluation (the reference has no distributed code).
+ * One process per GPU; every rank owns a handle holding a contiguous TIME SLICE of the batch
+ * (cmax_set_events with have_tminmax = 1 and the batch-wide extremes) and one RCCL communicator.
+ * The collectives are enqueued by the library on the caller's stream, between its own kernels:
+ *   K1 votes of this slice -> all-reduce(sum) of [n_images, Hp, Wp] fp32 (all reference times and the
+ *   un-warped image in ONE call) -> contrast statistics + loss (redundantly, identical on every rank)
+ *   + K3 gather of this slice's events -> all-reduce(sum) of the gradient (fp64 [2] | fp32 [2,H,W] |
+ *   fp32 [T,2,H,W]).  No other exchange; no host synchronisation.
+ * RCCL is bound at run time (the librccl already in the process, i.e. torch's, else ROCm's); a handle
+ * without a communicator -- or with nranks == 1 -- never touches it.
+ * ============================================================================================= */
+#define CMAX_COMM_ID_BYTES 128
+/* rank 0: a fresh rendezvous id (ncclGetUniqueId) into id_host[128]; ship it to the other ranks
+ * by any means (torch.distributed broadcast, a file, MPI).                                      */
+int cmax_comm_unique_id(void *id_host);
+/* Collective over the ranks (blocks until all nranks processes have called): binds the handle's
+ * device (the current HIP device must be the one the handle was created on) to rank `rank`.
+ * nranks == 1 with id_host == NULL: no communicator, RCCL is never loaded; with an id a real 1-rank
+ * communicator is made (cmax_objective_dist then runs the N > 1 enqueue sequence, RCCL included). */
+int cmax_comm_init(cmax_handle_t h, const void *id_host, int nranks, int rank);
+int cmax_comm_destroy(cmax_handle_t h);
+/* nranks / rank of the handle's communicator (1 / 0 without one); rccl_version: ncclGetVersion, 0
+ * if RCCL was never loaded.                                                                      */
+int cmax_comm_info(cmax_handle_t h, int *nranks, int *rank, int *rccl_version);
+/* In-place all-reduce of a device buffer on the handle's communicator (dtype CMAX_F32 / CMAX_F64;
+ * op 0 sum, 1 min, 2 max) -- e.g. (t_min, -t_max) with op min to agree on the batch extremes.   */
+int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, int op, cmax_stream_t stream);
+/* One evaluation of the whole (time-sliced) batch: same arguments and results as cmax_objective,
+ * the same on every rank (the gradient bit for bit; the loss up to fp64 summation order when a rank
+ * holds no events).  A rank may hold zero events.  Without a communicator: == cmax_objective.   */
+int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+                        double *result, void *grad, cmax_stream_t stream);
+
 /* Per-kernel-class timing for bench.py's roofline: when enabled every launch of the four hot kernels
  * is bracketed by HIP events ON THE LAUNCH STREAM.  enable = 1: one launch per bracket (results stay
  * valid; the bracket adds ~2.5 us of marker/dispatch latency to a ~8 us kernel).  enable = R in 2..64:
@@ -267,6 +302,10 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, co
  * 2 = K2b gradient image, 3 = K3 per-event gradient (host arrays of 4), and resets.           */
 int cmax_set_profiling(cmax_handle_t h, int enable);
 int cmax_read_profile(cmax_handle_t h, double *total_ms_host, int64_t *count_host);
+/* The same with every class (host arrays of CMAX_PROF_CLASSES): 0..3 as above, 4 = finishing kernels
+ * (k_finish*, k_finalize), 5 = RCCL collectives (never repeated inside a bracket).                 */
+#define CMAX_PROF_CLASSES 6
+int cmax_read_profile_all(cmax_handle_t h, double *total_ms_host, int64_t *count_host);
 
 /* sizeof(cmax_objective_t) as compiled into the library (binding self-check).                 */
 int cmax_sizeof_objective(void);

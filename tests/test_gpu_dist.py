@@ -1,0 +1,165 @@
+"""GPU tests of the time-sliced multi-GPU path as far as ONE GPU can take it (the GPU boxes of the test tier
+have one MI355X; RCCL refuses two ranks on one device):
+
+* a world-1 `nccl` process group + a REAL 1-rank RCCL communicator inside libcmax_hip.so: cmax_objective_dist then
+  runs the N > 1 enqueue sequence (vote -> ncclAllReduce(images) -> finish -> ncclAllReduce(gradient)) and must
+  reproduce cmax_objective;
+* two handles holding the two time slices of one batch, combined by hand the way the all-reduces would, against the
+  oracle (incl. an EMPTY slice: a rank may hold no events);
+* bench.py's N > 1 code path end to end (self-launch of 2 ranks sharing the GPU, gloo, torch collectives).
+The world-2 logic (partition, extremes, both exchange steps) runs under gloo on CPU: tests/test_distributed_gloo.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+import event_based_optical_flow_amd as E  # noqa: E402
+from event_based_optical_flow_amd.distributed import TimeSlicedObjective  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def world1_nccl():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+CASES = [
+    ("2d-translation", "image_variance", 0.0, 0),
+    ("2d-translation", "multi_focal_normalized_gradient_magnitude", 1.0, 0),
+    ("dense-flow", "gradient_magnitude", 0.0, 0),
+    ("dense-flow", "normalized_image_variance", 1.0, 0),
+    ("dense-flow-voxel", "image_variance", 1.0, 5),
+]
+
+
+def _motion(model, size, Tn):
+    if model == "2d-translation":
+        return np.array([9.0, -6.0])
+    if model == "dense-flow":
+        return E.utils.generate_smooth_flow(size, 10, seed=5)
+    return np.stack([E.utils.generate_smooth_flow(size, 10, seed=5 + b) for b in range(Tn)])
+
+
+@pytest.mark.parametrize("model,cost,sigma,Tn", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
+def test_objective_dist_world1_rccl(world1_nccl, model, cost, sigma, Tn):
+    """cmax_objective_dist on a real 1-rank RCCL communicator == cmax_objective (and == the oracle)."""
+    size, n = (96, 128), 120_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=11)
+    motion = _motion(model, size, Tn)
+    desc = E.make_descriptor(cost, model, sigma=sigma, time_bin=Tn)
+    h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
+    res, grad = h.evaluate(desc, motion)
+    assert h.comm_info() == (1, 0, 0)
+    h.comm_init(force_rccl=True)
+    nranks, rank, version = h.comm_info()
+    assert (nranks, rank) == (1, 0) and version > 0, "RCCL was not bound"
+    for _ in range(3):  # double-buffered images, cached un-warped image: repeat
+        res_d, grad_d = h.evaluate_dist(desc, motion)
+    torch.cuda.synchronize()
+    assert abs(res_d[0].item() - res[0].item()) <= 1e-9 * abs(res[0].item())
+    assert rel_max(grad_d.cpu().numpy(), grad.cpu().numpy()) <= 2e-6  # fp32 atomics: order differs run to run
+    ref = orc.objective(ev, motion, model, size, cost=cost, sigma=int(sigma))
+    assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grad_d.cpu().numpy(), ref["grad"]) <= TOL
+    # the raw collective entry: a 1-rank all-reduce leaves the buffer as it is
+    t = torch.arange(8, dtype=torch.float64, device="cuda")
+    h.comm_allreduce(t, "min")
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))
+    h.comm_destroy()
+    assert h.comm_info() == (1, 0, 0)
+
+
+def test_time_sliced_objective_world1_group(world1_nccl):
+    """TimeSlicedObjective under an initialised nccl group of world size 1: no exchange step, device-side extremes."""
+    size, n = (64, 80), 40_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=12)
+    obj = TimeSlicedObjective(E.CMaxHandle(size))
+    assert obj.collectives == "none"
+    obj.set_local_events(torch.from_numpy(ev).cuda(), device="cuda")
+    desc = E.make_descriptor("image_variance", "2d-translation")
+    res, grad = obj.evaluate(desc, np.array([7.0, -3.0]))
+    ref = orc.objective(ev, np.array([7.0, -3.0]), "2d-translation", size, cost="image_variance", sigma=0)
+    assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
+
+
+@pytest.mark.parametrize("split", [0.5, 1.0], ids=["halves", "second-slice-empty"])
+@pytest.mark.parametrize("model,cost", [("2d-translation", "image_variance"), ("dense-flow", "gradient_magnitude")])
+def test_two_slices_combined_like_the_allreduces(model, cost, split):
+    """Two handles = the two ranks of a world-2 run (global t_min / t_max, phase-split API, images and gradients summed
+    the way C1 / C2 do) against the oracle on the whole batch.  A slice may be EMPTY."""
+    size, n = (96, 128), 100_001
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=13)
+    motion = _motion(model, size, 0)
+    desc = E.make_descriptor(cost, model)
+    cut = int(n * split)
+    tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
+    ranks = [E.CMaxHandle(size).set_events(ev[:cut], tmin, tmax), E.CMaxHandle(size).set_events(ev[cut:], tmin, tmax)]
+    assert ranks[1].n_events == n - cut
+    images = sum(h.objective_vote(desc, motion) for h in ranks)
+    outs = [h.objective_finish(desc, motion, images) for h in ranks]
+    ref = orc.objective(ev, motion, model, size, cost=cost, sigma=0)
+    for res, _ in outs:  # the loss is the whole batch's on every rank
+        assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    gsum = sum(g.double() for _, g in outs).cpu().numpy()
+    assert rel_max(gsum, ref["grad"]) <= TOL
+
+
+def test_vote_finish_interleaved_through_temporaries():
+    """vote(A), vote(B), finish(A) through temporary fp32 motion copies -- the caching allocator may hand
+    B's copy the address A's had.  The stand-alone finish must not trust windows published for another motion."""
+    size, n = (96, 128), 150_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=14)
+    h = E.CMaxHandle(size).set_events(ev)
+    desc = E.make_descriptor("image_variance", "2d-translation")
+    A, B = np.array([25.0, -18.0]), np.array([-30.0, 22.0])  # windows of A and B do not overlap
+    img_a = h.objective_vote(desc, A).clone()
+    h.objective_vote(desc, B)
+    res, grad = h.objective_finish(desc, A, img_a)
+    ref = orc.objective(ev, A, "2d-translation", size, cost="image_variance", sigma=0)
+    assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
+
+
+def test_bench_two_ranks_on_one_gpu_self_launched():
+    """`python bench.py --gpus 2` without a launcher must start its own ranks.  Both ranks share cuda:0
+    (RCCL cannot do that: gloo + torch collectives), tiny step counts: this checks the N > 1 plumbing and the JSON line."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "5", "--warmup", "2",
+           "--windows", "3", "--no-also", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["events_per_gpu"] == 1_000_000
+    assert out["config"]["collectives"].startswith("torch.distributed")
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0

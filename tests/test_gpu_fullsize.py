@@ -1,0 +1,96 @@
+"""Full-size parity: the BASELINE configurations at THEIR sizes against the fp64 oracle.
+
+Above ~2.1M events the host switches the event kernels to 512-thread workgroups (1024 for the voxel K3); these tests
+run exactly the instantiations the bench numbers come from -- t256 2-DoF deferred (cfg2), t512 dense grad-mag
+(cfg3), t1024 voxel with blur (cfg4), t512 dense variance on a sparse 720p batch (cfg5 shard) -- and compare IWE,
+loss and gradient with oracle/cmax_oracle.c (scalar C, ~6e7 events/s: seconds per case).
+
+Tolerance (BASELINE north_star): 1e-4 relative, fp32 device path against the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import event_based_optical_flow_amd as E  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+TOL = 1e-4
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def check(tag, h, res, grad, ref, iwe_key="iwe"):
+    e_iwe = rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"][iwe_key])
+    e_loss = abs(res[0].item() - ref["loss"]) / abs(ref["loss"])
+    e_grad = rel_max(grad.double().cpu().numpy(), ref["grad"])
+    print(f"[fullsize] {tag}: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e}")
+    assert e_iwe <= TOL and e_loss <= TOL and e_grad <= TOL, (tag, e_iwe, e_loss, e_grad)
+
+
+def test_cfg2_full_size_bench_workload():
+    """EXACTLY what bench.py times: 1M uniform events (seed 46), 260x346, theta = (12.3, -7.7), variance, sigma 0."""
+    size, n = (260, 346), 1_000_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    theta = np.array([12.3, -7.7])
+    h = E.CMaxHandle(size).set_events(ev)
+    res, grad = h.evaluate(E.make_descriptor("image_variance", "2d-translation"), theta)
+    ref = orc.objective(ev, theta, "2d-translation", size, cost="image_variance", sigma=0)
+    check("cfg2 1M 260x346 2-DoF variance", h, res, grad, ref)
+
+
+def test_cfg3_full_size_dense_gradmag():
+    """5M events, 480x640, dense smooth flow, gradient magnitude: t512 K1 / K3 <dense, grad-mag (kFoldScale)>."""
+    size, n = (480, 640), 5_000_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
+    h = E.CMaxHandle(size).set_events(ev)
+    res, grad = h.evaluate(E.make_descriptor("gradient_magnitude", "dense-flow"), flow)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="gradient_magnitude", sigma=0)
+    check("cfg3 5M 480x640 dense grad-mag", h, res, grad, ref)
+
+
+def test_cfg4_full_size_burgers_voxel():
+    """2M events, 260x346, Burgers voxel T = 10 (t0 middle), variance with sigma 1: t512 K1, t1024 voxel K3."""
+    size, n, Tn = (260, 346), 2_000_000, 10
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    f0 = E.utils.generate_smooth_flow(size, 20, seed=1046)
+    voxel = orc.construct_dense_flow_voxel(f0 / 20.0, Tn, "burgers", "middle") * 20.0
+    h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
+    res, grad = h.evaluate(E.make_descriptor("image_variance", "dense-flow-voxel", sigma=1.0, time_bin=Tn), voxel)
+    ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=1)
+    check("cfg4 2M 260x346 voxel T=10 sigma 1", h, res, grad, ref)
+
+
+def test_cfg5_shard_full_size_with_gradient():
+    """One rank's share of cfg5: 2.5M events on 720x1280 (2.7 events per pixel), dense flow, variance + gradient."""
+    size, n = (720, 1280), 2_500_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
+    h = E.CMaxHandle(size).set_events(ev)
+    res, grad = h.evaluate(E.make_descriptor("image_variance", "dense-flow"), flow)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
+    check("cfg5 shard 2.5M 720x1280 dense variance", h, res, grad, ref)
+
+
+def test_cfg5_two_time_slices_of_5m_against_the_oracle():
+    """cfg5's exchange pattern at a size the oracle does in seconds: 5M events on 720x1280 as two 2.5M-event time
+    slices with the batch-wide extremes, images and gradients summed like C1 / C2, against the oracle on all 5M."""
+    size, n = (720, 1280), 5_000_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=47)
+    flow = E.utils.generate_smooth_flow(size, 20, seed=1047)
+    desc = E.make_descriptor("image_variance", "dense-flow")
+    tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
+    ranks = [E.CMaxHandle(size).set_events(ev[: n // 2], tmin, tmax), E.CMaxHandle(size).set_events(ev[n // 2:], tmin, tmax)]
+    images = sum(h.objective_vote(desc, flow) for h in ranks)
+    outs = [h.objective_finish(desc, flow, images) for h in ranks]
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
+    gsum = sum(g.double() for _, g in outs).cpu().numpy()
+    e_iwe = rel_max(images[0].cpu().numpy(), ref["iwes"]["iwe"])
+    e_loss = abs(outs[0][0][0].item() - ref["loss"]) / abs(ref["loss"])
+    e_grad = rel_max(gsum, ref["grad"])
+    print(f"[fullsize] cfg5 2 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e}")
+    assert e_iwe <= TOL and e_loss <= TOL and e_grad <= TOL

@@ -114,7 +114,8 @@ def test_cfg2_2dof_variance_structured():
 
 def test_cfg2_2dof_variance_uniform_random():
     """Documented worst case (SURVEY.md section 7 hard part 2): uniform-random events, the gradient
-    is a heavily cancelling sum.  The integer-base/displacement split keeps it inside 1e-4."""
+    is a heavily cancelling sum.  The integer-base/displacement split keeps it inside 1e-4 (the bench workload
+    itself, 1M events, is tests/test_gpu_fullsize.py::test_cfg2_full_size_bench_workload)."""
     size, n = (260, 346), 300_000
     ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
     theta = np.array([12.3, -7.7])
@@ -122,8 +123,7 @@ def test_cfg2_2dof_variance_uniform_random():
     loss, grads, h = fused_eval(size, ev, theta, "2d-translation", "image_variance", 0)
     assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
-    scale = np.abs(ref["grad"]).max()
-    assert np.abs(grads[0] - ref["grad"]).max() <= 1e-3 * scale, (grads[0], ref["grad"])
+    assert rel_max(grads[0], ref["grad"]) <= TOL, (grads[0], ref["grad"])
 
 
 def test_cfg3_dense_gradmag():
@@ -174,7 +174,7 @@ def test_odd_image_size_and_repeated_evaluations(model, cost, sigma):
         loss = obj(m)
         (grad,) = torch.autograd.grad(loss, m)
         assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"]), it
-        assert rel_max(grad.cpu().numpy(), ref["grad"]) <= 2 * TOL, it
+        assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL, it
 
 
 def test_cfg4_burgers_voxel_variance():
