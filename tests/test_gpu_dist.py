@@ -81,7 +81,7 @@ def test_objective_dist_world1_rccl(world1_nccl, model, cost, sigma, Tn):
     for _ in range(3):  # double-buffered images, cached un-warped image: repeat
         res_d, grad_d = h.evaluate_dist(desc, motion)
     torch.cuda.synchronize()
-    assert abs(res_d[0].item() - res[0].item()) <= 1e-9 * abs(res[0].item())
+    assert abs(res_d[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())  # the vote flush is fp32 atomics: order varies
     assert rel_max(grad_d.cpu().numpy(), grad.cpu().numpy()) <= 2e-6  # fp32 atomics: order differs run to run
     ref = orc.objective(ev, motion, model, size, cost=cost, sigma=int(sigma))
     assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])

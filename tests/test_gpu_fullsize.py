@@ -5,7 +5,13 @@ run exactly the instantiations the bench numbers come from -- t256 2-DoF deferre
 (cfg3), t1024 voxel with blur (cfg4), t512 dense variance on a sparse 720p batch (cfg5 shard) -- and compare IWE,
 loss and gradient with oracle/cmax_oracle.c (scalar C, ~6e7 events/s: seconds per case).
 
-Tolerance (BASELINE north_star): 1e-4 relative, fp32 device path against the fp64 oracle."""
+Tolerance (BASELINE north_star): 1e-4 relative, fp32 device path against the fp64 oracle -- for the IWE, the loss and
+the gradient.  One refinement for the gradient, explained and computed in tests/_border.py: the handful of events whose
+warped coordinate lies within fp32 rounding of a bilinear cell border take their derivative from the neighbouring cell
+in any fp32 evaluation (the objective's gradient is discontinuous there); their possible contribution is bounded in
+fp64 from the oracle's own intermediates and added to the gate, element-wise:  |g - g_ref| <= 1e-4 max|g_ref| + bound.
+For the 2-DoF gradient (a sum over ALL events, so the bound is not local) the same batch is evaluated a second time
+without those few tens of events, where the plain 1e-4 gate must hold."""
 import numpy as np
 import pytest
 import torch
@@ -15,6 +21,8 @@ pytestmark = pytest.mark.gpu
 import event_based_optical_flow_amd as E  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
+from _border import MARGIN, ambiguity_bound, raw_image_grad  # noqa: E402
+
 TOL = 1e-4
 
 
@@ -23,12 +31,21 @@ def rel_max(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def check(tag, h, res, grad, ref, iwe_key="iwe"):
-    e_iwe = rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"][iwe_key])
+def check(tag, h, res, grad, ref, bound=None, n_amb=0):
+    """bound: element-wise slack for cell-border events (tests/_border.py), or None for the plain 1e-4 gate."""
+    e_iwe = rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"])
     e_loss = abs(res[0].item() - ref["loss"]) / abs(ref["loss"])
-    e_grad = rel_max(grad.double().cpu().numpy(), ref["grad"])
-    print(f"[fullsize] {tag}: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e}")
-    assert e_iwe <= TOL and e_loss <= TOL and e_grad <= TOL, (tag, e_iwe, e_loss, e_grad)
+    g = grad.double().cpu().numpy()
+    gmax = np.abs(ref["grad"]).max()
+    err = np.abs(g - ref["grad"])
+    e_grad = err.max() / gmax
+    slack = 0.0 if bound is None else 1.01 * bound
+    e_gate = ((err - slack).max()) / gmax  # what is left after the border events' own terms
+    n_over = int((err > TOL * gmax).sum())
+    print(f"[fullsize] {tag}: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e} | gated {e_gate:.2e} "
+          f"({n_over} of {err.size} gradient entries above 1e-4, {n_amb} cell-border events)")
+    assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL, (tag, e_iwe, e_loss, e_grad, e_gate)
+    assert n_over <= 2 * max(n_amb, 0), (tag, n_over, n_amb)  # every entry above the gate belongs to a border event
 
 
 def test_cfg2_full_size_bench_workload():
@@ -39,7 +56,19 @@ def test_cfg2_full_size_bench_workload():
     h = E.CMaxHandle(size).set_events(ev)
     res, grad = h.evaluate(E.make_descriptor("image_variance", "2d-translation"), theta)
     ref = orc.objective(ev, theta, "2d-translation", size, cost="image_variance", sigma=0)
-    check("cfg2 1M 260x346 2-DoF variance", h, res, grad, ref)
+    bound, n_amb = ambiguity_bound(ev, theta, "2d-translation", size, raw_image_grad(ref, 0))
+    check("cfg2 1M 260x346 2-DoF variance", h, res, grad, ref, bound, n_amb)
+    # the same stream without its cell-border events (their time extremes are kept): plain 1e-4
+    warped, _ = orc.warp_event(ev, theta, "2d-translation", "first", size)
+    frac = np.mod(warped[:, :2] + 1e-6, 1.0)
+    keep = (np.minimum(frac, 1.0 - frac) >= MARGIN).all(axis=1)
+    keep[[0, -1]] = True
+    ev2 = ev[keep]
+    assert 0 < len(ev) - len(ev2) < 200
+    h2 = E.CMaxHandle(size).set_events(ev2)
+    res2, grad2 = h2.evaluate(E.make_descriptor("image_variance", "2d-translation"), theta)
+    ref2 = orc.objective(ev2, theta, "2d-translation", size, cost="image_variance", sigma=0)
+    check(f"cfg2 without its {len(ev) - len(ev2)} cell-border events", h2, res2, grad2, ref2)
 
 
 def test_cfg3_full_size_dense_gradmag():
@@ -50,7 +79,8 @@ def test_cfg3_full_size_dense_gradmag():
     h = E.CMaxHandle(size).set_events(ev)
     res, grad = h.evaluate(E.make_descriptor("gradient_magnitude", "dense-flow"), flow)
     ref = orc.objective(ev, flow, "dense-flow", size, cost="gradient_magnitude", sigma=0)
-    check("cfg3 5M 480x640 dense grad-mag", h, res, grad, ref)
+    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    check("cfg3 5M 480x640 dense grad-mag", h, res, grad, ref, bound, n_amb)
 
 
 def test_cfg4_full_size_burgers_voxel():
@@ -62,7 +92,8 @@ def test_cfg4_full_size_burgers_voxel():
     h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
     res, grad = h.evaluate(E.make_descriptor("image_variance", "dense-flow-voxel", sigma=1.0, time_bin=Tn), voxel)
     ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=1)
-    check("cfg4 2M 260x346 voxel T=10 sigma 1", h, res, grad, ref)
+    bound, n_amb = ambiguity_bound(ev, voxel, "dense-flow-voxel", size, raw_image_grad(ref, 1))
+    check("cfg4 2M 260x346 voxel T=10 sigma 1", h, res, grad, ref, bound, n_amb)
 
 
 def test_cfg5_shard_full_size_with_gradient():
@@ -73,7 +104,8 @@ def test_cfg5_shard_full_size_with_gradient():
     h = E.CMaxHandle(size).set_events(ev)
     res, grad = h.evaluate(E.make_descriptor("image_variance", "dense-flow"), flow)
     ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
-    check("cfg5 shard 2.5M 720x1280 dense variance", h, res, grad, ref)
+    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    check("cfg5 shard 2.5M 720x1280 dense variance", h, res, grad, ref, bound, n_amb)
 
 
 def test_cfg5_two_time_slices_of_5m_against_the_oracle():
@@ -91,6 +123,10 @@ def test_cfg5_two_time_slices_of_5m_against_the_oracle():
     gsum = sum(g.double() for _, g in outs).cpu().numpy()
     e_iwe = rel_max(images[0].cpu().numpy(), ref["iwes"]["iwe"])
     e_loss = abs(outs[0][0][0].item() - ref["loss"]) / abs(ref["loss"])
+    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    gmax = np.abs(ref["grad"]).max()
     e_grad = rel_max(gsum, ref["grad"])
-    print(f"[fullsize] cfg5 2 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e}")
-    assert e_iwe <= TOL and e_loss <= TOL and e_grad <= TOL
+    e_gate = (np.abs(gsum - ref["grad"]) - 1.01 * bound).max() / gmax
+    print(f"[fullsize] cfg5 2 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e} | gated {e_gate:.2e} "
+          f"({n_amb} cell-border events)")
+    assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL

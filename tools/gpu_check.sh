@@ -11,10 +11,15 @@ for line in open("gpurun_out/bench_$wl.log"):
     if line.startswith("{"):
         d = json.loads(line)
         r = d["roofline"]
-        print("$wl value %.3e ev/s  ms/step %.4f  dominant %s %.1f us frac %.3f  all %s  eval_frac %.3f  cpu %s" % (
-            d["value"], d["ms_per_step"], r["kernel"].split()[0], r["launch_us"], r["frac"],
-            {k: round(v, 1) for k, v in r["all_kernels_us"].items()}, r["evaluation_frac"],
+        print("$wl value %.3e ev/s  ms/step %.4f (min %.4f max %.4f)  eval frac %.3f  dominant %s %.1f us frac %.3f  kernels %s  cpu %s" % (
+            d["value"], d["ms_per_step"], d["timing"]["min"], d["timing"]["max"], r["frac"], r["dominant"]["kernel"].split()[0],
+            r["dominant"]["launch_us"], r["dominant"]["frac"],
+            {k: round(v.get("launch_us", v.get("single_launch_bracket_us")), 1) for k, v in r["kernels"].items()},
             ("%.2e" % d["cpu_baseline"]["value"]) if "cpu_baseline" in d else "-"))
+        for k, a in d.get("also", {}).items():
+            print("   also %s: ms/step %.4f value %.3e eval frac %.3f dominant %s %.1f us frac %.3f  kernels %s" % (
+                k, a["ms_per_step"], a["value"], a["evaluation_frac"], (a["dominant_kernel"] or "-").split()[0], a["dominant_kernel_us"] or 0,
+                a["dominant_kernel_frac"] or 0, {q: round(v, 1) for q, v in a["kernels_us"].items()}))
         break
 else:
     print(open("gpurun_out/bench_$wl.log").read()[-2000:])
