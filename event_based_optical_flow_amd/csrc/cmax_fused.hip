@@ -33,6 +33,7 @@
 // fp32 per event with the integer source pixel split from the fp32 displacement (keeps the
 // bilinear fractions accurate to ulp(displacement) instead of ulp(coordinate)); fp64 reductions.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -50,7 +51,8 @@ constexpr int kSegMax = 2040;                 // events per segment (+1 for the 
                                               // |sum of votes| <= 2040 * 2^20 < 2^31
 constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit words (32 KiB)
 static_assert(kSegMax <= 2040, "fixed-point vote accumulation would overflow");
-constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (dense / voxel K3)
+constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (voxel K3): 12 (tile, bin) groups
+constexpr int kAccCellsDense = 768;           // the same for the dense K3 with owned tiles: 3 source tiles
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
 constexpr float kFix = 1048576.f;             // 2^20: votes are accumulated as signed 12.20 fixed point
 constexpr float kInvFix = 1.f / 1048576.f;
@@ -116,6 +118,7 @@ struct cmax_handle_s {
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] source pixels with >= 1 event
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
+    bool owned = false;      // the work list gives every group (empty ones included) to exactly one segment, <= kAccCells / 256 groups each
     int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int4 *d_win = nullptr;        // [4][nseg] LDS windows of the last objective vote (K1 -> K3 of the same evaluation)
@@ -362,8 +365,12 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
     } else if (MODEL == CMAX_MODEL_DENSE || MODEL == CMAX_MODEL_VOXEL) {
         const int hw = wp.H * wp.W;
         if (MODEL == CMAX_MODEL_VOXEL) w.src += (int)(pk >> 24) * 2 * hw;
-        dx = fmaf(-w.dt, wp.motion[w.src], dx);  // x' = x - dt*F[0,ix,iy], src/warp.py:305-306
-        dy = fmaf(-w.dt, wp.motion[w.src + hw], dy);
+        // uniform base + unsigned 32-bit BYTE offset: one address instruction per event and a `global_load_dword v, voff, s[base]`
+        // per channel, instead of 64-bit per-lane pointer arithmetic (the field is < 4 GiB: checked by the host)
+        const unsigned off = (unsigned)w.src * 4u;
+        const char *m0 = reinterpret_cast<const char *>(wp.motion), *m1 = reinterpret_cast<const char *>(wp.motion + hw);
+        dx = fmaf(-w.dt, *reinterpret_cast<const float *>(m0 + off), dx);  // x' = x - dt*F[0,ix,iy], src/warp.py:305-306
+        dy = fmaf(-w.dt, *reinterpret_cast<const float *>(m1 + off), dy);
     }
     // floor(x' + 1e-6) = ix + floor(dx + 1e-6) exactly because ix is an integer
     // (bilinear_vote_tensor, src/event_image_converter.py:340-345)
@@ -401,6 +408,7 @@ struct Window {
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
 constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3;  // kFoldScale: G image stored without its chain factor
+constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2;  // k_grad's VARIANT (see cmax_event_kernels.inc)
 constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
@@ -450,6 +458,10 @@ __device__ __forceinline__ float dpp_f(float v) {  // lanes whose source is outs
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int old, int v) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u0(unsigned v) {  // lanes without a source read 0 (bound_ctrl: no move of the identity first)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
 constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
@@ -1103,6 +1115,11 @@ static float ref_fraction(int ref_mode, double frac) {
 // 512-thread workgroups (4 events per thread) once the work list exceeds what the chip holds at once
 // (the voxel K3 then even 1024 x 2)
 static bool wide_groups(const cmax_handle_s *h) { return h->nseg > 1024; }
+// tuning experiments only: CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024 force the workgroup size of K1 / K3
+static int forced_ns(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
 
 template <int MODEL>
 static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, hipStream_t s) {
@@ -1110,8 +1127,9 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     ProfScope prof(h, kProfVote, s);
 #define CMAX_LAUNCH_VOTE(NS, FRAC) \
     hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra)
+    static const int force = forced_ns("CMAX_VOTE_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (wide_groups(h)) {
+        if (force ? force == 512 : wide_groups(h)) {
             if (h->has_frac) CMAX_LAUNCH_VOTE(t512, true);
             else CMAX_LAUNCH_VOTE(t512, false);
         } else {
@@ -1124,24 +1142,33 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 
 template <int MODEL>
 static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, int fold,
-                        const ObjParams &op, double *gpart, float *gflow, double *result, hipStream_t s) {
+                        const ObjParams &op, double *gpart, float *gflow, double *result, bool owned, hipStream_t s) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     ProfScope prof(h, kProfGrad, s);
     // dense model: runs of equal source pixel are reduced serially per thread when they are long (pixel-sorted
-    // handle, >= 8 events per active pixel), else with a segmented scan per slot over lanes holding consecutive events
+    // handle, >= 8 events per active pixel), else with a segmented scan per slot over lanes holding consecutive events;
+    // owned groups (dense / voxel, one reference time, group-aligned work list): LDS accumulators + plain stores
     const bool strided = MODEL == CMAX_MODEL_DENSE && !(h->long_runs && h->n_time_bin == 0);
-#define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, STRIDED) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, STRIDED>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
+#define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, VARIANT) \
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
     do {                                                                      \
         if constexpr (MODEL == CMAX_MODEL_DENSE) {                            \
-            if (strided) {                                                    \
-                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, true);                     \
+            if (owned) {                                                      \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwned);               \
+            } else if (strided) {                                             \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradStrided);             \
             } else {                                                          \
-                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false);                    \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradRuns);                \
+            }                                                                 \
+        } else if constexpr (MODEL == CMAX_MODEL_VOXEL) {                     \
+            if (owned) {                                                      \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwned);               \
+            } else {                                                          \
+                CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradRuns);                \
             }                                                                 \
         } else {                                                              \
-            CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, false);                        \
+            CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradRuns);                    \
         }                                                                     \
     } while (0)
 #define CMAX_LAUNCH_GRAD_FR(NS, FRAC)                                                        \
@@ -1160,12 +1187,13 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     } else {                             \
         CMAX_LAUNCH_GRAD_FR(NS, false)   \
     }
+    static const int force = forced_ns("CMAX_GRAD_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (MODEL == CMAX_MODEL_VOXEL && wide_groups(h)) {  // measured: voxel K3 of cfg4 22.1 us (512 threads) -> 19.3 us
+        if (force ? (force == 1024 && MODEL == CMAX_MODEL_VOXEL) : (MODEL == CMAX_MODEL_VOXEL && wide_groups(h))) {  // measured: voxel K3 of cfg4 22.1 us (512 threads) -> 19.3 us
             if constexpr (MODEL == CMAX_MODEL_VOXEL) {
                 CMAX_LAUNCH_GRAD_NS(t1024)
             }
-        } else if (wide_groups(h)) {
+        } else if (force ? force >= 512 : h->nseg > 512) {  // K3 hides its latencies better with 8 waves per workgroup (cfg2: 7.5 -> 7.1 us)
             CMAX_LAUNCH_GRAD_NS(t512)
         } else {
             CMAX_LAUNCH_GRAD_NS(t256)
@@ -1384,12 +1412,37 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     if (h->n < (int64_t)256 * kSegMax) seg_cap = (int)std::min<int64_t>(kSegMax, std::max<int64_t>(256, (h->n + 511) / 512));
     if (T > 1 && seg_cap < kSparseSegment) max_groups = std::max(max_groups, 3 * T);
     std::vector<int4> segs;
+    // Owned groups (batches of at least one full segment per CU whose groups all fit a segment): every group -- empty
+    // ones included -- belongs to exactly ONE segment made of whole consecutive groups of one tile row, at most 3 tiles
+    // (LDS window) / kAccCells / 256 groups (LDS accumulators).  The flow-gradient kernel of a single-reference objective
+    // then stores its groups' pixels instead of adding to them (k_grad, kGradOwned), and the buffer needs no clearing.
+    h->owned = false;
+    if (h->n >= (int64_t)256 * kSegMax && !getenv("CMAX_NO_OWNED")) {
+        bool fits = true;
+        for (int g = 0; g < ngroups && fits; ++g) fits = group_start[g + 1] - group_start[g] <= kSegMax;
+        h->owned = fits;
+    }
+    if (h->owned) {
+        const int span_max = T == 1 ? 3 : kAccCells / 256, row_groups = h->ntc * T;
+        for (int r0 = 0; r0 < ngroups; r0 += row_groups) {
+            int g = r0;
+            while (g < r0 + row_groups) {
+                const int gs = g;
+                int cnt = 0;
+                while (g < r0 + row_groups && g - gs < span_max && cnt + (group_start[g + 1] - group_start[g]) <= kSegMax) {
+                    cnt += group_start[g + 1] - group_start[g];
+                    ++g;
+                }
+                segs.push_back(make_int4(group_start[gs], cnt, gs, g - gs));
+            }
+        }
+    }
     int begin = 0, count = 0, row_of_begin = -1, g0 = 0, g_last = 0;
     auto close = [&]() {
         if (count > 0) segs.push_back(make_int4(begin, count, g0, g_last - g0 + 1));
         count = 0;
     };
-    for (int g = 0; g < ngroups; ++g) {
+    for (int g = 0; g < ngroups && !h->owned; ++g) {
         int b = group_start[g], c = group_start[g + 1] - group_start[g];
         const int trow = (g / T) / h->ntc;
         if (c == 0) continue;
@@ -1663,6 +1716,8 @@ static int check_objective_args(cmax_handle_t h, const cmax_objective_t *d, cons
     CMAX_REQUIRE(d->n_ref >= 1 && d->n_ref <= 4, "objective: n_ref");
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || (d->T > 0 && d->T == h->n_time_bin), "objective: voxel T must match the handle's time bins");
     CMAX_REQUIRE(!d->omit_boundary || (h->Hp > 2 && h->Wp > 2), "objective: image too small for omit_boundary");
+    CMAX_REQUIRE((int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W * 4 < ((int64_t)1 << 32),
+                 "objective: the motion field must be smaller than 4 GiB (32-bit byte offsets in the event kernels)");
     return 0;
 }
 
@@ -1752,7 +1807,12 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // gradient magnitude with a gradient: K2 and K2b (and the blurs) are one kernel: statistics + G image without its chain factor
     const bool fused_gm = grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
     const bool blur_var = d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
-    const bool grad_cleared_by_stats = grad && !two_dof && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
+    // owned groups: K3 stores every element of the flow gradient itself (one writer per pixel) -- nothing to clear.
+    // Needs the group-aligned work list, ONE reference time (several would add into the same pixels) and the sort
+    // order that matches the model (dense: tiles; voxel: (tile, bin) of the same T).
+    const bool owned = grad && h->owned && h->n > 0 && d->n_ref == 1 &&
+                       ((d->model == CMAX_MODEL_DENSE && h->n_time_bin == 0) || (d->model == CMAX_MODEL_VOXEL && h->n_time_bin == d->T));
+    const bool grad_cleared_by_stats = grad && !two_dof && !owned && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
     float4 *clear4 = grad_cleared_by_stats ? (float4 *)grad : nullptr;
     const int64_t nclear4 = grad_cleared_by_stats ? gcount / 4 : 0;
     double k0 = 0, k1 = 0;
@@ -1797,7 +1857,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
 
     // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
-    if (!two_dof && !grad_cleared_by_stats) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+    if (!two_dof && !grad_cleared_by_stats && !owned) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
     const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : (fused_gm ? kFoldScale : kFoldNone));
     if (blur_var) {
         ImgArgs ib = ia;
@@ -1833,9 +1893,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
     double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
     switch (d->model) {
-        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, h->d_gpart, nullptr, res, s); break;
-        case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, s); break;
-        default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, s); break;
+        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, h->d_gpart, nullptr, res, false, s); break;
+        case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
+        default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
     }
     CMAX_CHECK_LAUNCH();
     if (deferred) {
