@@ -16,6 +16,7 @@ from . import _lib
 from . import functional as F
 from ._lib import CmaxObjective, check
 from .array_types import to_device_tensor
+from .costs.hybrid import combine
 
 _COST_TABLE = {
     # name: (cost code, normalized, [(direction, multiplier), ...])  -- which IWEs get_arg_for_cost builds
@@ -353,21 +354,27 @@ class ContrastObjective:
                                        warp_direction)
                 self.terms.append((name, weight, desc))
 
-    @property
-    def has_exact_hvp(self) -> bool:
-        """True when H v is available from cmax_objective_hvp: every fused term with a numeric weight
-        (total_variation is piecewise linear: zero Hessian almost everywhere)."""
-        return all(weight != "inv" for _, weight, _ in self.terms)
+    has_exact_hvp = True  # every fused term, numeric and "inv" weights (total_variation does not depend on `motion`)
 
     def hvp(self, motion: torch.Tensor, vector: torch.Tensor) -> torch.Tensor:
-        """Exact Hessian-vector product w.r.t. `motion` (same shape/dtype as motion)."""
-        if not self.has_exact_hvp:
-            raise NotImplementedError("exact HVP is not built for 'inv'-weighted hybrid terms")
+        """Exact Hessian-vector product w.r.t. `motion` (same shape/dtype as motion).  A term of weight w contributes
+        w * H_c v (cmax_objective_hvp); an "inv" term phi(c) = 1 / c contributes phi' H_c v + phi'' <grad c, v> grad c
+        with c and grad c from one cmax_objective call (src/costs/hybrid.py:51-53 differentiated twice)."""
+        from .costs.hybrid import combine_derivatives
+
         out = None
+        v64 = to_device_tensor(vector, "vector").detach().to(torch.float64)
         for name, weight, desc in self.terms:
             if desc is None:
-                continue  # total_variation: zero a.e.
-            hv = self.handle.hvp(desc, motion, vector).to(torch.float64) * float(weight)
+                continue  # total_variation acts on the coarse flow, not on `motion`
+            hv = self.handle.hvp(desc, motion, vector).to(torch.float64)
+            if weight == "inv":
+                res, grad = self.handle.evaluate(desc, motion, want_grad=True)
+                p1, p2 = combine_derivatives("inv", res[0])
+                g64 = grad.to(torch.float64).reshape(v64.shape)
+                hv = p1 * hv + p2 * (g64 * v64).sum() * g64.reshape(hv.shape)
+            else:
+                hv = hv * float(weight)
             out = hv if out is None else out + hv
         if out is None:
             out = torch.zeros_like(vector, dtype=torch.float64)
@@ -385,5 +392,5 @@ class ContrastObjective:
             else:
                 value = _FusedFn.apply(motion, self.handle, desc)
             value = value.to(motion.device) if isinstance(motion, torch.Tensor) else value
-            loss = loss + (1.0 / value if weight == "inv" else weight * value)
+            loss = loss + combine(weight, value)
         return loss

@@ -151,36 +151,54 @@ class PatchFlowObjective:
         """TorchWrapper calls `hvp_numpy` / `hvp` when this is True.  Time-ignorant objectives: patch -> dense is linear,
         so H_x = t^2 P^T H_flow P.  Time-aware objectives add the second-order adjoint of the Burgers / upwind voxel
         chain (cmax_voxel_construct_tan / _adj_tan).  The total-variation term is piecewise linear: zero Hessian
-        almost everywhere (a difference quotient of the whole objective would push its kinks into the curvature)."""
+        almost everywhere (a difference quotient of the whole objective would push its kinks into the curvature); with an
+        "inv" weight it still contributes its rank-one part phi'' <grad TV, v> grad TV."""
         return self.contrast.has_exact_hvp
 
     def _smooth_grad(self, x: torch.Tensor) -> torch.Tensor:
         """Gradient of the contrast terms (everything except total_variation) w.r.t. x."""
+        from ..cmax import _FusedFn
+        from ..costs.hybrid import combine
+
         xt = x.detach().clone().requires_grad_()
         loss = 0.0
         for name, weight, desc in self.contrast.terms:
             if desc is None:
                 continue
-            from ..cmax import _FusedFn
-
-            loss = loss + float(weight) * _FusedFn.apply(self.dense_flow(xt), self.handle, desc)
+            loss = loss + combine(weight, _FusedFn.apply(self.dense_flow(xt), self.handle, desc))
         (g,) = torch.autograd.grad(loss, xt)
         return g
 
+    def _tv_inverse_curvature(self, x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """Second-order part of an "inv"-weighted total_variation term: phi'' <grad TV, v> grad TV (H_TV = 0 a.e.)."""
+        from ..costs.hybrid import combine_derivatives
+
+        out = torch.zeros_like(x)
+        for name, weight, desc in self.contrast.terms:
+            if desc is not None or weight != "inv":
+                continue
+            xt = x.detach().clone().requires_grad_()
+            tv = F.total_variation(xt.reshape((2,) + self.patch_image_size), self.contrast.omit_boundary)
+            if self.contrast.direction != "minimize":
+                tv = -tv
+            (g,) = torch.autograd.grad(tv, xt)
+            _, p2 = combine_derivatives("inv", tv.detach())
+            out = out + p2 * (g * v).sum() * g
+        return out
+
     def hvp(self, x: torch.Tensor, v: torch.Tensor, disp_step: float = 0.05) -> torch.Tensor:
         """Hessian-vector product w.r.t. the patch motion x on tensors (the autograd-chained path; TorchWrapper prefers
-        `hvp_numpy`, which is exact for both kinds).  Time-ignorant: exact, composed from the autograd-wrapped stages.
-        Time-aware: a central difference of the analytic gradient of the smooth part (disp_step in pixels of
-        displacement over the batch)."""
-        if not self.has_exact_hvp:
-            raise NotImplementedError("no HVP for 'inv'-weighted hybrid terms")
+        `hvp_numpy`, which is exact for both kinds).  Time-ignorant: exact, composed from the autograd-wrapped stages
+        ("inv" weights included).  Time-aware: a central difference of the analytic gradient of the smooth part
+        (disp_step in pixels of displacement over the batch)."""
         x = x.to(self.handle.device)
-        v = v.to(self.handle.device)
+        v = v.to(self.handle.device).to(x.dtype)
+        tv_part = self._tv_inverse_curvature(x, v)
         if self.time_aware:
             # step measured in PIXELS OF DISPLACEMENT over the batch (x is pixel per time unit): a fixed
             # 0.05 px keeps the quotient above the fp32 noise of the gradient and below the pixel scale
             h = disp_step / (self.t_scale * float(v.abs().max()))
-            return (self._smooth_grad(x + h * v) - self._smooth_grad(x - h * v)) / (2.0 * h)
+            return (self._smooth_grad(x + h * v) - self._smooth_grad(x - h * v)) / (2.0 * h) + tv_part
         shape = (2,) + self.patch_image_size
         size, sw, pad = self.handle.image_size, self.sliding_window, self.pad
         dense = F.patch_to_dense(x.detach().reshape(shape), size, sw, pad) * self.t_scale
@@ -190,7 +208,7 @@ class PatchFlowObjective:
         probe = x.detach().reshape(shape).clone().requires_grad_()
         out = F.patch_to_dense(probe, size, sw, pad)
         (hx,) = torch.autograd.grad(out, probe, grad_outputs=hflow.contiguous())
-        return (hx * self.t_scale).reshape(x.shape)
+        return (hx * self.t_scale).reshape(x.shape) + tv_part
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         x = x.to(self.handle.device)

@@ -513,6 +513,165 @@ def gen_patch_search():
     save("patch_search", **out)
 
 
+def _ref_pyramid_solver(H, W, time_aware, scale=4, crop=(64, 80)):
+    """The reference's PyramidalPatchContrastMaximization with the shipped YAML parameters
+    (configs/mvsec_indoor_no_timeaware.yaml / mvsec_indoor_burgers.yaml) on an H x W sensor."""
+    from src import solver as ref_solver
+
+    slv_cfg = {
+        "method": "pyramidal_patch_contrast_maximization", "time_aware": time_aware,
+        "patch": {"initialize": "random", "scale": scale, "crop_height": crop[0], "crop_width": crop[1], "filter_type": "bilinear"},
+        "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
+        "cost": "hybrid", "outer_padding": 0,
+        "cost_with_weight": {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+        "iwe": {"method": "bilinear_vote", "blur_sigma": 1},
+    }
+    if time_aware:
+        slv_cfg.update({"time_bin": 10, "flow_interpolation": "burgers", "t0_flow_location": "middle"})
+    opt_cfg = {"n_iter": 40, "method": "Newton-CG", "max_iter": 25,
+               "parameters": {"trans_x": {"min": -150, "max": 150}, "trans_y": {"min": -150, "max": 150}}}
+    slv = ref_solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
+    slv._device = "cpu"
+    return slv
+
+
+def _moving_dot_events(n, H, W, flow_fn, rng, n_dots, period=0.05, jitter=0.5):
+    """Events of dots that move with the displacement field flow_fn(x, y) -> (vx, vy) in pixel per batch period:
+    an event emitted at time t sits at centre + (t / period) * v(centre).  Integer pixel coordinates, sorted in t."""
+    t = np.sort(rng.uniform(0.0, period, n))
+    dot = rng.integers(0, n_dots, n)
+    cx, cy = rng.uniform(4, H - 4, n_dots), rng.uniform(4, W - 4, n_dots)
+    vx, vy = flow_fn(cx, cy)
+    x = cx[dot] + (t / period) * vx[dot] + rng.normal(0, jitter, n)
+    y = cy[dot] + (t / period) * vy[dot] + rng.normal(0, jitter, n)
+    ev = np.empty((n, 4))
+    ev[:, 0] = np.clip(np.round(x), 0, H - 1)
+    ev[:, 1] = np.clip(np.round(y), 0, W - 1)
+    ev[:, 2] = t
+    ev[:, 3] = rng.integers(0, 2, n)
+    return ev
+
+
+def gen_solver_optimize():
+    """An OPTIMISER RESULT of the reference: run_scipy at the coarsest scale (src/solver/patch_contrast_pyramid.py:252-318
+    with scale 1: seeded start, no Optuna, no skimage) = scipy_autograd.minimize(objective_scipy, x0, "Newton-CG",
+    {gtol 1e-5, maxiter 25, eps 0.01}, float64) -> solver_optimize.npz: x0, final x, final loss, iteration counts, for the
+    plain and the Burgers YAML objective.  Scene: dots moving with a smooth 2 x 2-patch flow (so the optimum is meaningful)."""
+    from src.solver import scipy_autograd
+
+    rng = np.random.default_rng(SEED + 5)
+    H, W = 68, 90
+    period = 0.05
+
+    def flow_fn(cx, cy):  # pixel per batch period, smooth across the sensor
+        return 6.0 + 4.0 * cx / H - 2.0 * cy / W, -5.0 + 3.0 * cy / W + 2.0 * cx / H
+
+    ev = _moving_dot_events(20000, H, W, flow_fn, rng, n_dots=150, period=period)
+    out = {"events": ev, "image_size": np.array([H, W]), "period": np.array(period), "seed": np.array(SEED + 5),
+           "shims": np.array(ref_import.SHIMS)}
+    te = torch.from_numpy(ev)
+    for tag, time_aware in (("plain", False), ("burgers", True)):
+        slv = _ref_pyramid_solver(H, W, time_aware)
+        slv.overload_patch_configuration(1)
+        ph, pw = slv.patch_image_size
+        # the reference's x is pixel / second, and the flow it describes is the NEGATIVE scene velocity
+        # (interpolate_dense_flow_from_patch_tensor negates): start within +-30 % of (-8, 3) px per batch on every patch.
+        # With this start the reference's own run is stable -- perturbing x0 by 1e-7 relative moves its end point by
+        # < 0.005 px and its final loss by < 4e-6 relative (checked when the fixture was made); a start far from the
+        # optimum is not (the objective has kinks at every pixel-cell border, Newton-CG's line search amplifies them)
+        base = -np.array([[8.0] * (ph * pw), [-3.0] * (ph * pw)]).reshape(-1) / period
+        x0 = base * (1.0 + 0.3 * rng.uniform(-1.0, 1.0, 2 * ph * pw))
+        res = scipy_autograd.minimize(lambda x: slv.objective_scipy(x, te, {}, suppress_log=True), x0, method="Newton-CG",
+                                      options={"gtol": 1e-5, "disp": False, "maxiter": 25, "eps": 0.01}, precision="float64",
+                                      torch_device="cpu")
+        dense = slv.interpolate_dense_flow_from_patch_tensor(torch.from_numpy(np.asarray(res.x).reshape(-1)))
+        out[tag + "__x0"] = x0
+        out[tag + "__x"] = np.asarray(res.x).reshape(-1)
+        out[tag + "__loss0"] = np.array(slv.objective_scipy(torch.from_numpy(x0), te, {}, suppress_log=True).item())
+        out[tag + "__loss"] = np.array(float(res.fun))
+        out[tag + "__nit"] = np.array(int(res.nit))
+        out[tag + "__nfev"] = np.array(int(res.nfev))
+        out[tag + "__dense"] = dense.numpy()  # pixel / second
+        out[tag + "__patch_image_size"] = np.array([ph, pw])
+        out[tag + "__patch_size"] = np.array(slv.patch_size)
+        out[tag + "__sliding_window"] = np.array(slv.sliding_window)
+        out[tag + "__patch_shift"] = np.array(slv.patch_shift)
+        print(tag, "loss0", float(out[tag + "__loss0"]), "->", float(res.fun), "nit", res.nit, "nfev", res.nfev, "x", np.round(res.x * period, 2))
+    save("solver_optimize", **out)
+
+
+def gen_solver_objective_cfg1():
+    """BASELINE configs[0] at ITS size: 260 x 346 sensor, 30 000 events, the shipped YAML (patch scale 4 -> 16 x 16
+    patches at the finest scale, hybrid cost): value and gradient of objective_scipy at scales 1 (coarsest) and 4
+    (finest), plain and Burgers -> solver_objective_cfg1.npz"""
+    rng = np.random.default_rng(SEED + 6)
+    H, W = 260, 346
+
+    def flow_fn(cx, cy):
+        return 8.0 * np.sin(cx / 60.0) + 3.0, -6.0 * np.cos(cy / 80.0)
+
+    ev = _moving_dot_events(30000, H, W, flow_fn, rng, n_dots=600)
+    out = {"events": ev, "image_size": np.array([H, W]), "seed": np.array(SEED + 6), "shims": np.array(ref_import.SHIMS)}
+    te = torch.from_numpy(ev)
+    for tag, time_aware in (("plain", False), ("burgers", True)):
+        slv = _ref_pyramid_solver(H, W, time_aware, scale=5, crop=(256, 336))  # configs/mvsec_indoor_*.yaml: scale 5, crop 256 x 336
+        for scale in (1, 4):
+            slv.overload_patch_configuration(scale)
+            ph, pw = slv.patch_image_size
+            x = rng.uniform(-200, 200, 2 * ph * pw)  # pixel / second: +-10 px over the 0.05 s batch
+            tx = torch.from_numpy(x).requires_grad_()
+            loss = slv.objective_scipy(tx, te, {}, suppress_log=True)
+            (g,) = torch.autograd.grad(loss, tx)
+            k = f"{tag}_s{scale}"
+            out[k + "__x"] = x
+            out[k + "__loss"] = np.array(loss.item())
+            out[k + "__grad"] = g.numpy()
+            out[k + "__patch_image_size"] = np.array([ph, pw])
+            out[k + "__patch_size"] = np.array(slv.patch_size)
+            out[k + "__sliding_window"] = np.array(slv.sliding_window)
+            print(k, "patches", ph, pw, "loss", loss.item())
+        out[tag + "__patch_shift"] = np.array(slv.patch_shift)
+    save("solver_objective_cfg1", **out)
+
+
+def gen_hvp_inv():
+    """Hybrid costs with an "inv" weight (src/costs/hybrid.py:51-53: the term contributes 1 / cost): value, gradient and
+    vhp of the objective w.r.t. the motion, inputs of objective.npz -> hvp_inv.npz"""
+    g = dict(np.load(os.path.join(HERE, "objective.npz")))
+    H, W = (int(v) for v in g["image_size"])
+    te = torch.from_numpy(g["events"])
+    rng = np.random.default_rng(SEED + 7)
+    out = {}
+    cases = [("2dof", "2d-translation", "theta", {"image_variance": "inv"}),
+             ("2dof", "2d-translation", "theta", {"gradient_magnitude": 1.0, "image_variance": "inv"}),
+             ("dense_smooth", "dense-flow", "flow_smooth", {"normalized_gradient_magnitude": "inv", "image_variance": 0.5})]
+    for ci, (mname, model, mkey, cww) in enumerate(cases):
+        fs = _fake_solver(H, W, "hybrid", 1, cost_with_weight=cww)
+
+        def f(m):
+            arg = PatchContrastMaximization.get_arg_for_cost(fs, te, m, model, None)
+            return fs.cost_func.calculate(arg)
+
+        x = torch.from_numpy(g[mkey])
+        v = torch.from_numpy(rng.normal(size=x.shape))
+        loss, hv = torch.autograd.functional.vhp(f, x, v)
+        xg = x.clone().requires_grad_()
+        (grad,) = torch.autograd.grad(f(xg), xg)
+        tag = f"case{ci}"
+        out[tag + "__model"] = np.array(model)
+        out[tag + "__motion_key"] = np.array(mkey)
+        out[tag + "__costs"] = np.array(list(cww.keys()))
+        out[tag + "__weights"] = np.array([str(w) for w in cww.values()])
+        out[tag + "__v"] = v.numpy()
+        out[tag + "__vhp"] = hv.numpy()
+        out[tag + "__grad"] = grad.numpy()
+        out[tag + "__loss"] = np.array(loss.item())
+        print(tag, model, cww, float(loss), float(hv.abs().max()))
+    out["shims"] = np.array(ref_import.SHIMS)
+    out["seed"] = np.array(SEED + 7)
+    np.savez_compressed(os.path.join(HERE, "hvp_inv.npz"), **out)
+
+
 def gen_core():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
@@ -527,9 +686,10 @@ def gen_core():
 
 
 if __name__ == "__main__":
-    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search]   (no argument = everything)
+    # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search] [solver_optimize]
+    #                                    [solver_cfg1] [hvp_inv]                                   (no argument = everything)
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
-                                                                    "patch_search"]
+                                                                    "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -542,3 +702,9 @@ if __name__ == "__main__":
         gen_solver_hvp()
     if "patch_search" in which:
         gen_patch_search()
+    if "solver_optimize" in which:
+        gen_solver_optimize()
+    if "solver_cfg1" in which:
+        gen_solver_objective_cfg1()
+    if "hvp_inv" in which:
+        gen_hvp_inv()

@@ -230,3 +230,46 @@ def test_torch_cpu_restatement_matches_the_c_oracle(golden, model, cost):
     np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=1e-11 * np.abs(ref["grad"]).max())
     tag = ("2dof" if model == "2d-translation" else "dense_smooth") + f"__{cost}__s0"
     assert abs(loss - g[tag + "__loss"]) <= 1e-10 * abs(g[tag + "__loss"])
+
+
+# ---- round 2 fixtures: BASELINE configs[0] at its own size, "inv" hybrid weights, a pinned optimiser result ------------
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
+@pytest.mark.parametrize("scale", [1, 4])
+def test_solver_objective_cfg1_size(golden, tag, scale):
+    """objective_scipy of the shipped YAML at 260 x 346 / 30 000 events / 2 x 2 and 16 x 16 patches."""
+    g = golden("solver_objective_cfg1")
+    k = f"{tag}_s{scale}"
+    size = tuple(int(v) for v in g["image_size"])
+    loss, grad = orc.solver_objective(g["events"], g[k + "__x"], size, g[k + "__patch_image_size"], g[k + "__patch_size"],
+                                      g[k + "__sliding_window"], g[tag + "__patch_shift"], cost="hybrid",
+                                      cost_with_weight=YAML_HYBRID_SOLVER, sigma=1, time_aware=(tag == "burgers"))
+    np.testing.assert_allclose(loss, g[k + "__loss"], rtol=1e-10)
+    ref = g[k + "__grad"]
+    np.testing.assert_allclose(grad, ref, rtol=1e-7, atol=1e-10 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_hybrid_inverse_weights(golden, case):
+    """A member with weight "inv" contributes 1 / cost (src/costs/hybrid.py:51-53): loss and autograd gradient."""
+    g, o = golden("hvp_inv"), golden("objective")
+    k = f"case{case}"
+    cww = {str(n): (w if w == "inv" else float(w)) for n, w in zip(g[k + "__costs"], (str(x) for x in g[k + "__weights"]))}
+    size = tuple(int(v) for v in o["image_size"])
+    ref = orc.objective(o["events"], o[str(g[k + "__motion_key"])], str(g[k + "__model"]), size, cost="hybrid", sigma=1, cost_with_weight=cww)
+    np.testing.assert_allclose(ref["loss"], g[k + "__loss"], rtol=1e-10)
+    np.testing.assert_allclose(ref["grad"], g[k + "__grad"], rtol=1e-7, atol=1e-10 * np.abs(g[k + "__grad"]).max())
+
+
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
+def test_pinned_optimizer_result_is_a_minimum_of_the_oracle(golden, tag):
+    """solver_optimize.npz = the reference's run_scipy at the coarsest scale (Newton-CG).  The oracle reproduces the
+    loss at its start and end points, and the end point is (nearly) stationary for the oracle's gradient."""
+    g = golden("solver_optimize")
+    size = tuple(int(v) for v in g["image_size"])
+    args = (size, g[tag + "__patch_image_size"], g[tag + "__patch_size"], g[tag + "__sliding_window"], g[tag + "__patch_shift"])
+    kw = dict(cost="hybrid", cost_with_weight=YAML_HYBRID_SOLVER, sigma=1, time_aware=(tag == "burgers"))
+    l0, g0 = orc.solver_objective(g["events"], g[tag + "__x0"], *args, **kw)
+    l1, g1 = orc.solver_objective(g["events"], g[tag + "__x"], *args, **kw)
+    np.testing.assert_allclose(l0, g[tag + "__loss0"], rtol=1e-10)
+    np.testing.assert_allclose(l1, g[tag + "__loss"], rtol=1e-10)
+    assert l1 < l0 and np.abs(g1).max() < 0.1 * np.abs(g0).max()
