@@ -169,6 +169,8 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     ev, motion, T = make_inputs(cfg, rank, world, structured=args.events == "structured")
     n_local = ev.shape[0]
     handle = E.CMaxHandle((H, W))
+    if args.deterministic:
+        handle.set_deterministic(True)
     sliced = TimeSlicedObjective(handle, in_library=not args.torch_collectives)
     ev_dev = torch.from_numpy(ev).to(dev)  # fp64 [n,4] resident in HBM before anything is timed
     sliced.set_local_events(ev_dev, time_bin=T, device=dev)  # first call: workspace allocation, code-object load
@@ -220,7 +222,7 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
            "ms_per_step": elapsed / steps * 1e3, "value": n_total * steps / elapsed,
            "window_ms_per_step": {"min": float(times[0]) / steps * 1e3, "median": elapsed / steps * 1e3, "max": float(times[-1]) / steps * 1e3,
                                   "windows": windows, "steps_per_window": steps},
-           "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives}
+           "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives, "deterministic": bool(args.deterministic)}
     if world > 1:
         out["rccl"] = dict(zip(("nranks", "rank", "version"), handle.comm_info()))
     # B / t_eval.  Per GPU: N/g events + the full images (every rank evaluates the image-space part)
@@ -312,6 +314,7 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: all-reduce with torch.distributed around the phase-split calls instead of inside the library")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (1-GPU box testing with --backend gloo)")
+    ap.add_argument("--deterministic", action="store_true", help="cmax_set_deterministic(1): integer accumulation, bit-repeatable results (slower)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -376,7 +379,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (%s events, seed 46)" % args.events,
             "config": {"workload": cfg["desc"], "events_per_gpu": n, "image": [H, W], "motion_model": cfg["model"],
-                       "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}",
+                       "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}", "deterministic": bool(args.deterministic),
                        "collectives": None if world == 1 else main_res["collectives"] + ": all-reduce(IWE) + all-reduce(grad) per evaluation",
                        "rccl": main_res.get("rccl")},
             "timing": dict(main_res["window_ms_per_step"], statistic="median window; every window = `steps` evaluations between barrier + "

@@ -111,6 +111,8 @@ SIGNATURES = {
     "cmax_objective_hvp": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_vote": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "cmax_set_deterministic": (c_int, [c_vp, c_int]),
+    "cmax_get_deterministic": (c_int, [c_vp, ctypes.POINTER(c_int)]),
     "cmax_comm_unique_id": (c_int, [c_vp]),
     "cmax_comm_init": (c_int, [c_vp, c_vp, c_int, c_int]),
     "cmax_comm_destroy": (c_int, [c_vp]),

@@ -202,6 +202,19 @@ class CMaxHandle:
                                               grad.data_ptr() if grad is not None else None, F._stream()))
         return result, grad
 
+    # -- deterministic mode ------------------------------------------------------------------------------------
+    def set_deterministic(self, enable: bool = True):
+        """Bit-identical IWE / loss / gradient from run to run (cmax_set_deterministic): integer accumulation wherever the
+        order of events, workgroups or atomics would otherwise show in the last bits.  Slower; see include/cmax_hip.h."""
+        check(self._lib.cmax_set_deterministic(self._h, int(bool(enable))))
+        return self
+
+    @property
+    def deterministic(self) -> bool:
+        v = ctypes.c_int(0)
+        check(self._lib.cmax_get_deterministic(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
     # -- in-library collectives (RCCL over xGMI, see distributed.py) -------------------------------------
     def comm_init(self, group=None, force_rccl: bool = False):
         """Give this handle an RCCL communicator over the ranks of the torch.distributed `group` (default: the

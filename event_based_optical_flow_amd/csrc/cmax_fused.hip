@@ -84,6 +84,12 @@ struct RefArgs {
     float *zero[4];   // K3, deferred statistics: vote image of the NEXT evaluation to clear (or null)
     int k0;           // index of the first reference time of this launch (statistics slot, partial-sum offset)
     int4 *win;        // [n_ref][nseg] LDS windows: written by K1, read by K3 of the same evaluation (or null)
+    // deterministic mode (cmax_set_deterministic): order-free integer accumulation
+    long long *img64[4];       // K1: 2^-20 fixed-point vote image, 64-bit integer atomics instead of fp32 ones (or null)
+    const unsigned *imax;      // K3: bits of max |image k| per statistics slot (the bound the fixed-point scale is derived from)
+    long long *g64;            // K3: 2-DoF per-segment partial sums [n_ref][nseg][2] / flow-gradient accumulators, fixed point
+    double *det_inv_scale;     // K3: [4] 1 / scale used by reference time k (2-DoF) or by all of them ([0], flow gradient)
+    long long n_events;        // K3: events behind one accumulator at most (fixed-point headroom)
 };
 
 // the image-space kernels of an evaluation cover all reference times in one launch as well (blockIdx.y)
@@ -165,6 +171,15 @@ struct cmax_handle_s {
     std::vector<hipEvent_t> prof_ev[CMAX_PROF_CLASSES];  // class -> [start0, stop0, start1, stop1, ...]
     // time-sliced multi-GPU evaluation: this rank's RCCL communicator (cmax_comm_init), or null
     cmax::Comm *comm = nullptr;
+    // deterministic mode (cmax_set_deterministic): every accumulation that depends on the order of events, workgroups or
+    // atomics is done in integers (exact, associative) -- bit-identical IWE, loss and gradient from run to run
+    bool deterministic = false;
+    long long *img64 = nullptr;   // [5][npix] fixed-point vote images, all zero between evaluations
+    unsigned *d_imax = nullptr;   // [kStatSlots] bits of max |image| per statistics slot
+    long long *g64 = nullptr;     // fixed-point gradient accumulators (zero between evaluations)
+    int64_t g64_cap = 0;
+    double *d_det_inv_scale = nullptr;  // [4]
+    float *Gt_det = nullptr;      // [4][npix] dL/d(blurred image) of the unfused image path
 };
 
 namespace cmax {
@@ -408,7 +423,7 @@ struct Window {
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
 constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3;  // kFoldScale: G image stored without its chain factor
-constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2;  // k_grad's VARIANT (see cmax_event_kernels.inc)
+constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2, kGradDet = 3;  // k_grad's VARIANT (see cmax_event_kernels.inc)
 constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
@@ -1006,6 +1021,85 @@ k_gimage_tan(const float *__restrict__ img, const float *__restrict__ dimg, ObjP
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// deterministic mode: fixed-point conversions
+// ---------------------------------------------------------------------------------------------
+// power-of-two scale s with  bound * n * s < 2^61: n terms of magnitude <= bound fit a 64-bit accumulator
+__device__ __forceinline__ double det_scale(double bound, long long n) {
+    int e = 0;
+    (void)frexp(bound * (double)(n > 0 ? n : 1), &e);  // bound n = f 2^e, f in [0.5, 1); 0 -> e = 0
+    if (!(bound >= 0.0) || e > 1000) e = 1000;         // NaN / inf: any finite scale
+    return ldexp(1.0, 60 - e);
+}
+__device__ __forceinline__ void atomic_add_i64(long long *p, long long v) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);  // two's complement: wrap-around add
+}
+
+// fixed-point vote images -> fp32 images (blockIdx.y = image), the integer image is left zero for the next evaluation
+struct FixedArgs {
+    long long *src[5];
+    float *dst[5];
+};
+__global__ void __launch_bounds__(256) k_fixed_to_image(FixedArgs fa, int64_t npix) {
+    long long *__restrict__ src = fa.src[blockIdx.y];
+    float *__restrict__ dst = fa.dst[blockIdx.y];
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        const long long v = src[p];
+        dst[p] = (float)((double)v * (1.0 / 1048576.0));  // one rounding, of the exact sum
+        if (v != 0) src[p] = 0;
+    }
+}
+
+// max |image| of one statistics slot (order-free: integer max of the magnitude bits); imax[slot] zeroed by the caller
+__global__ void __launch_bounds__(256) k_image_absmax(ImgArgs ia, int64_t npix, int slot0, unsigned *__restrict__ imax) {
+    const float *__restrict__ img = ia.in[blockIdx.y];
+    unsigned m = 0u;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(img[p]) & 0x7FFFFFFFu);
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&imax[slot0 + blockIdx.y], m);
+}
+
+// fixed-point flow gradient -> fp32 (x 1 / scale), accumulators left zero
+__global__ void __launch_bounds__(256) k_fixed_to_grad(long long *__restrict__ g64, float *__restrict__ grad, int64_t n, const double *__restrict__ inv_scale) {
+    const double is = inv_scale[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long v = g64[i];
+        grad[i] = (float)((double)v * is);
+        if (v != 0) g64[i] = 0;
+    }
+}
+
+// 2-DoF: gradient = sum over reference times and segments of the fixed-point partials (integer sums: any order)
+__global__ void __launch_bounds__(256) k_finish_det(long long *__restrict__ gpart64, int nseg, int n_ref, const double *__restrict__ inv_scale,
+                                                    double *__restrict__ gtheta) {
+    __shared__ long long s_acc[2];
+    double g0 = 0.0, g1 = 0.0;
+    for (int k = 0; k < n_ref; ++k) {
+        if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+        __syncthreads();
+        long long a0 = 0, a1 = 0;
+        long long *gp = gpart64 + (int64_t)k * nseg * 2;
+        for (int i = threadIdx.x; i < nseg; i += blockDim.x) {
+            a0 += gp[2 * i];
+            a1 += gp[2 * i + 1];
+        }
+        atomic_add_i64(&s_acc[0], a0);
+        atomic_add_i64(&s_acc[1], a1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            g0 += (double)s_acc[0] * inv_scale[k];  // reference times in fixed order
+            g1 += (double)s_acc[1] * inv_scale[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        gtheta[0] = g0;
+        gtheta[1] = g1;
+    }
+}
+
 }  // namespace cmax
 
 // the event kernels, once per workgroup size
@@ -1145,6 +1239,19 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
                         const ObjParams &op, double *gpart, float *gflow, double *result, bool owned, hipStream_t s) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     ProfScope prof(h, kProfGrad, s);
+    if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
+#define CMAX_LAUNCH_DET(FRAC, FOLD) \
+    hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
+        if (h->has_frac) {
+            if (fold == kFoldStats) CMAX_LAUNCH_DET(true, kFoldStats);
+            else CMAX_LAUNCH_DET(true, kFoldNone);
+        } else {
+            if (fold == kFoldStats) CMAX_LAUNCH_DET(false, kFoldStats);
+            else CMAX_LAUNCH_DET(false, kFoldNone);
+        }
+#undef CMAX_LAUNCH_DET
+        return;
+    }
     // dense model: runs of equal source pixel are reduced serially per thread when they are long (pixel-sorted
     // handle, >= 8 events per active pixel), else with a segmented scan per slot over lanes holding consecutive events;
     // owned groups (dense / voxel, one reference time, group-aligned work list): LDS accumulators + plain stores
@@ -1249,8 +1356,10 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
         for (int k = 0; k < n_ref; ++k) h->win_d[k] = ref_fraction(ref_mode[k], ref_frac[k]);
         h->win_generation = h->generation;
     }
+    const bool det = h->deterministic && h->n > 0;  // votes go to the integer images, imgs[k] are written by the conversion below
     for (int k = 0; k < n_ref; ++k) {
-        if (!((zero_mask >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(imgs[k], 0, npix * sizeof(float), s));
+        if (!det && !((zero_mask >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(imgs[k], 0, npix * sizeof(float), s));
+        if (det) ra.img64[k] = h->img64 + (int64_t)k * npix;
         double *stat_zero = stat_slot0 >= 0 ? h->d_stat + (stat_slot0 + k) * kStatStride : nullptr;
         if (h->n == 0 && stat_zero)  // no K1 launch on this rank: reset the accumulators explicitly
             CMAX_CHECK_HIP(hipMemsetAsync(stat_zero, 0, kStatStride * sizeof(double), s));
@@ -1268,6 +1377,15 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
         default: launch_vote<-1>(h, ev, wp, ra, n_ref, s); break;
     }
     CMAX_CHECK_LAUNCH();
+    if (det) {  // exact integer sums -> fp32 images, one rounding each; the integer images are zero again afterwards
+        FixedArgs fa = {};
+        for (int k = 0; k < n_ref; ++k) {
+            fa.src[k] = ra.img64[k];
+            fa.dst[k] = imgs[k];
+        }
+        hipLaunchKernelGGL(k_fixed_to_image, dim3(stream_grid(npix, 256), n_ref), dim3(256), 0, s, fa, npix);
+        CMAX_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -1293,6 +1411,8 @@ static int blur_image(cmax_handle_s *h, double sigma, const float *raw, float *b
 }
 
 static int stat_blocks(const cmax_handle_s *h) {
+    // deterministic mode: one workgroup per sub-accumulator, so every accumulator receives exactly one addition
+    if (h->deterministic) return kStatSub;
     // ~4 pixels per thread, at most kStatBlocksMax workgroups
     int64_t b = ((int64_t)h->Hp * h->Wp + 1023) / 1024;
     if (b < 1) b = 1;
@@ -1302,6 +1422,7 @@ static int stat_blocks(const cmax_handle_s *h) {
 
 // statistics of `img` -> stat[slot] (accumulators zeroed by the K1 launch); optionally zero `zero_img`
 static int stat_subs(const cmax_handle_s *h) {
+    if (h->deterministic) return kStatSub;
     int n = stat_blocks(h) / 12;  // ~12 same-address atomics per accumulator
     return n < 4 ? 4 : (n > kStatSub ? kStatSub : n);
 }
@@ -1598,6 +1719,11 @@ int cmax_destroy(cmax_handle_t h) {
     if (!h) return 0;
     comm_destroy(h->comm);
     h->comm = nullptr;
+    dev_free(&h->img64);
+    dev_free(&h->d_imax);
+    dev_free(&h->g64);
+    dev_free(&h->d_det_inv_scale);
+    dev_free(&h->Gt_det);
     dev_free(&h->imgs);
     for (int k = 0; k < 5; ++k) dev_free(&h->iweb[k]);
     dev_free(&h->G);
@@ -1803,16 +1929,19 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // the chain factors -- no K2 launch (unless a workgroup's slice of the image would get long)
     const bool two_dof = d->model == CMAX_MODEL_2DOF;
     const bool fold_var = d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0);
-    const bool deferred = grad && two_dof && fold_var && h->n > 0 && npix <= (int64_t)h->nseg * 8192;
+    // deterministic mode: the unfused image path (k_blur3, k_stats with one workgroup per accumulator, k_gimage, k_blur3_adj:
+    // every sum in a fixed order) and the integer-accumulating K3
+    const bool det = h->deterministic;
+    const bool deferred = !det && grad && two_dof && fold_var && h->n > 0 && npix <= (int64_t)h->nseg * 8192;
     // gradient magnitude with a gradient: K2 and K2b (and the blurs) are one kernel: statistics + G image without its chain factor
-    const bool fused_gm = grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
-    const bool blur_var = d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
+    const bool fused_gm = !det && grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
+    const bool blur_var = !det && d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
     // owned groups: K3 stores every element of the flow gradient itself (one writer per pixel) -- nothing to clear.
     // Needs the group-aligned work list, ONE reference time (several would add into the same pixels) and the sort
     // order that matches the model (dense: tiles; voxel: (tile, bin) of the same T).
-    const bool owned = grad && h->owned && h->n > 0 && d->n_ref == 1 &&
+    const bool owned = !det && grad && h->owned && h->n > 0 && d->n_ref == 1 &&
                        ((d->model == CMAX_MODEL_DENSE && h->n_time_bin == 0) || (d->model == CMAX_MODEL_VOXEL && h->n_time_bin == d->T));
-    const bool grad_cleared_by_stats = grad && !two_dof && !owned && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
+    const bool grad_cleared_by_stats = grad && !two_dof && !owned && !det && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
     float4 *clear4 = grad_cleared_by_stats ? (float4 *)grad : nullptr;
     const int64_t nclear4 = grad_cleared_by_stats ? gcount / 4 : 0;
     double k0 = 0, k1 = 0;
@@ -1857,8 +1986,42 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
 
     // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
-    if (!two_dof && !grad_cleared_by_stats && !owned) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+    if (!two_dof && !grad_cleared_by_stats && !owned && !det) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
     const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : (fused_gm ? kFoldScale : kFoldNone));
+    if (det) {
+        // bound of the per-event terms: max |image the contrast is evaluated on| per reference time (integer max: order-free)
+        CMAX_CHECK_HIP(hipMemsetAsync(h->d_imax, 0, kStatSlots * sizeof(unsigned), s));
+        ImgArgs im = {};
+        for (int k = 0; k < d->n_ref; ++k) im.in[k] = h->last_iwe[k];
+        hipLaunchKernelGGL(k_image_absmax, dim3(stream_grid(npix, 256), d->n_ref), dim3(256), 0, s, im, npix, 0, h->d_imax);
+        CMAX_CHECK_LAUNCH();
+        if (fold == kFoldNone) {  // dL/dIWE with its chain factor: k_gimage on the (blurred) image, then the blur transpose
+            if (d->sigma > 0 && !h->Gt_det) {
+                rc = dev_alloc(h, &h->Gt_det, 4 * npix);
+                if (rc) return rc;
+            }
+            float *gdst = d->sigma > 0 ? h->Gt_det : h->G;
+            const dim3 igrid(div_up(npix, 256), d->n_ref);
+            // the n_ref images are not contiguous (last_iwe[k] = blurred copies or the caller's buffer): one launch each
+            for (int k = 0; k < d->n_ref; ++k) {
+                if (d->cost == CMAX_COST_VARIANCE)
+                    hipLaunchKernelGGL(k_gimage<CMAX_COST_VARIANCE>, dim3(igrid.x), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, gdst + k * npix, (int64_t)0);
+                else
+                    hipLaunchKernelGGL(k_gimage<CMAX_COST_GRADMAG>, dim3(igrid.x), dim3(256), 0, s, h->last_iwe[k], op, k, h->d_stat, gdst + k * npix, (int64_t)0);
+            }
+            if (d->sigma > 0) hipLaunchKernelGGL(k_blur3_adj<float>, igrid, dim3(256), 0, s, h->Gt_det, Hp, Wp, (float)k0, (float)k1, h->G, npix);
+            CMAX_CHECK_LAUNCH();
+        }
+        if (!two_dof && gcount > h->g64_cap) {
+            CMAX_CHECK_HIP(hipStreamSynchronize(s));
+            dev_free(&h->g64);
+            h->g64_cap = 0;
+            rc = dev_alloc(h, &h->g64, gcount);
+            if (rc) return rc;
+            h->g64_cap = gcount;
+            CMAX_CHECK_HIP(hipMemsetAsync(h->g64, 0, (size_t)gcount * sizeof(long long), s));
+        }
+    }
     if (blur_var) {
         ImgArgs ib = ia;
         for (int k = 0; k < d->n_ref; ++k) ib.in[k] = h->iweb[k];
@@ -1889,6 +2052,12 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         same_vote = same_vote && h->win_d[k] == ra.d[k];
     }
     ra.win = same_vote ? h->d_win : nullptr;  // the windows K1 derived for exactly this warp
+    if (det) {
+        ra.imax = h->d_imax;
+        ra.g64 = two_dof ? reinterpret_cast<long long *>(h->d_gpart) : h->g64;  // (d_gpart: [4][nseg][6] doubles, 2 used per segment)
+        ra.det_inv_scale = h->d_det_inv_scale;
+        ra.n_events = h->n;
+    }
     const EvView ev = ev_view(h);
     const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
     double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
@@ -1898,7 +2067,14 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
     }
     CMAX_CHECK_LAUNCH();
-    if (deferred) {
+    if (det) {
+        ProfScope prof(h, kProfFinish, s);
+        if (two_dof)
+            hipLaunchKernelGGL(k_finish_det, dim3(1), dim3(256), 0, s, reinterpret_cast<long long *>(h->d_gpart), h->nseg, d->n_ref, h->d_det_inv_scale, (double *)grad);
+        else
+            hipLaunchKernelGGL(k_fixed_to_grad, dim3(stream_grid(gcount, 256)), dim3(256), 0, s, h->g64, (float *)grad, gcount, h->d_det_inv_scale);
+        CMAX_CHECK_LAUNCH();
+    } else if (deferred) {
         ProfScope prof(h, kProfFinish, s);
         hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_gpart, h->nseg, result, (double *)grad);
         CMAX_CHECK_LAUNCH();
@@ -1970,6 +2146,27 @@ int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *d, const float 
     if (rc) return rc;
     CMAX_REQUIRE(result, "objective_dist: result");
     return objective_eval(h, d, motion, result, grad, (hipStream_t)stream, h->comm);
+}
+
+int cmax_set_deterministic(cmax_handle_t h, int enable) {
+    CMAX_REQUIRE(h != nullptr, "set_deterministic: handle");
+    if (enable && !h->img64) {
+        const int64_t npix = (int64_t)h->Hp * h->Wp;
+        int rc = dev_alloc(h, &h->img64, 5 * npix);
+        if (!rc) rc = dev_alloc(h, &h->d_imax, kStatSlots);
+        if (!rc) rc = dev_alloc(h, &h->d_det_inv_scale, 4);
+        if (rc) return rc;
+        CMAX_CHECK_HIP(hipMemset(h->img64, 0, (size_t)5 * npix * sizeof(long long)));
+    }
+    h->deterministic = enable != 0;
+    h->win_generation = ~(uint64_t)0;  // windows published by the other mode's K1 stay valid, but keep the state simple
+    return 0;
+}
+
+int cmax_get_deterministic(cmax_handle_t h, int *enabled) {
+    CMAX_REQUIRE(h != nullptr && enabled != nullptr, "get_deterministic");
+    *enabled = h->deterministic ? 1 : 0;
+    return 0;
 }
 
 int cmax_comm_unique_id(void *id_host) {

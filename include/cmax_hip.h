@@ -293,6 +293,20 @@ int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, in
 int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
                         double *result, void *grad, cmax_stream_t stream);
 
+/* Deterministic mode ("race detection"): bit-identical IWE, loss and gradient from run
+ * to run for cmax_iwe / cmax_objective / cmax_objective_vote + _finish.  By default the vote flush, the flow
+ * gradient and the contrast statistics use floating-point atomics, whose order -- like the order of events inside
+ * a sorted group -- varies between runs, so results differ in their last bits (~1e-7 relative).  With enable != 0
+ * everything that depends on such an order is accumulated in INTEGERS: votes as 2^-20 fixed point in a 64-bit image
+ * (rounded to fp32 once), per-event gradient terms as 64-bit fixed point (scale from max |image|) added per thread,
+ * per workgroup and with 64-bit global atomics, statistics with one workgroup per accumulator and the unfused image
+ * kernels.  Same arithmetic per event, same parity (1e-4 of the reference); slower: no fused image kernels, one pair
+ * of global atomics per event for the flow gradient (dense 5M events: ~10x an evaluation), 40 B per pixel more HBM.
+ * Not covered: cmax_objective_hvp, the patch plan's own kernels; across ranks (cmax_objective_dist) the result is as
+ * repeatable as RCCL's reduction order.                                                                          */
+int cmax_set_deterministic(cmax_handle_t h, int enable);
+int cmax_get_deterministic(cmax_handle_t h, int *enabled);
+
 /* Per-kernel-class timing for bench.py's roofline: when enabled every launch of the four hot kernels
  * is bracketed by HIP events ON THE LAUNCH STREAM.  enable = 1: one launch per bracket (results stay
  * valid; the bracket adds ~2.5 us of marker/dispatch latency to a ~8 us kernel).  enable = R in 2..64:

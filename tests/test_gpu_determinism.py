@@ -1,0 +1,106 @@
+"""Deterministic mode (cmax_set_deterministic): bit-identical IWE, loss and gradient from run to run.
+
+By default the vote flush, the flow gradient and the statistics use floating-point atomics and the order of events inside
+a sorted group depends on atomics of the sort, so two evaluations of the same inputs differ in their last bits.  In
+deterministic mode every such sum is an integer sum.  Each case below packs the same batch into FRESH handles (the
+sort's own atomics reorder events between handles) and evaluates it several times; the outputs must be identical byte
+for byte, and still within 1e-4 of the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import event_based_optical_flow_amd as E  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+TOL = 1e-4
+CASES = [
+    ("2d-translation", "image_variance", 0.0, 0),
+    ("2d-translation", "multi_focal_normalized_gradient_magnitude", 1.0, 0),
+    ("dense-flow", "gradient_magnitude", 0.0, 0),
+    ("dense-flow", "normalized_image_variance", 1.0, 0),
+    ("dense-flow-voxel", "image_variance", 1.0, 6),
+    ("dense-flow-voxel", "multi_focal_normalized_image_variance", 0.0, 6),
+]
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _motion(model, size, Tn):
+    if model == "2d-translation":
+        return np.array([11.0, -7.0])
+    if model == "dense-flow":
+        return E.utils.generate_smooth_flow(size, 12, seed=21)
+    return np.stack([E.utils.generate_smooth_flow(size, 12, seed=21 + b) for b in range(Tn)])
+
+
+def _run(size, ev, desc, motion, Tn, deterministic):
+    h = E.CMaxHandle(size)
+    h.set_deterministic(deterministic)
+    assert h.deterministic == deterministic
+    h.set_events(ev, time_bin=Tn)
+    outs = []
+    defined = [0] + list(range(1, 1 + desc.n_ref)) + ([5] if desc.normalized else [])  # result[]: loss, v_k, v_orig (the rest is never written)
+    for _ in range(2):  # the second evaluation runs on the other vote buffer, with the cached un-warped image
+        res, grad = h.evaluate(desc, motion)
+        outs.append((res.cpu().numpy()[defined].tobytes(), grad.cpu().numpy().tobytes(), h.last_iwe(0).cpu().numpy().tobytes()))
+    return outs, res.cpu().numpy(), grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("model,cost,sigma,Tn", CASES, ids=[f"{c[0]}-{c[1]}-s{int(c[2])}" for c in CASES])
+def test_bit_repeatable(model, cost, sigma, Tn):
+    size, n = (180, 240), 400_000
+    if model == "2d-translation":
+        # moving dots: a 2-DoF gradient is ONE sum over all events, and on uniform-random events it cancels so far that the
+        # handful of cell-border events (tests/_border.py) shows at 1e-3 in either mode
+        ev = E.utils.generate_structured_events(n, size[0], size[1], (13.0, -8.0), n_dots=1200, seed=31)
+    else:
+        ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=31)
+    motion = _motion(model, size, Tn)
+    desc = E.make_descriptor(cost, model, sigma=sigma, time_bin=Tn)
+    runs = [_run(size, ev, desc, motion, Tn, True) for _ in range(3)]
+    first = runs[0][0][0]
+    for outs, _, _ in runs:
+        for o in outs:
+            assert o == first, "deterministic mode produced different bits"
+    res, grad = runs[0][1], runs[0][2]
+    ref = orc.objective(ev, motion, model, size, cost=cost, sigma=int(sigma))
+    assert abs(res[0] - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grad, ref["grad"]) <= TOL
+    # the default mode agrees with it to fp32 accumulation noise (and is allowed to differ in the last bits)
+    _, res_d, grad_d = _run(size, ev, desc, motion, Tn, False)
+    assert abs(res_d[0] - res[0]) <= 1e-6 * abs(res[0])
+    assert rel_max(grad_d, grad) <= 1e-5
+
+
+def test_default_mode_is_not_bit_repeatable_on_a_large_batch():
+    """Documents WHY the mode exists: fp32 atomics + the sort's ordering show in the last bits (if this ever starts to
+    pass bit-for-bit the default path became deterministic by itself -- fine, the assertion is one-sided)."""
+    size, n = (260, 346), 1_000_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    desc = E.make_descriptor("gradient_magnitude", "dense-flow")
+    flow = E.utils.generate_smooth_flow(size, 15, seed=5)
+    outs = [_run(size, ev, desc, flow, 0, False)[2] for _ in range(3)]
+    worst = max(rel_max(o, outs[0]) for o in outs[1:])
+    print(f"[determinism] default mode, three fresh handles: max relative gradient difference {worst:.2e}")
+    assert worst <= 1e-5
+
+
+def test_switching_modes_on_one_handle():
+    size, n = (96, 128), 80_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=33)
+    h = E.CMaxHandle(size).set_events(ev)
+    desc = E.make_descriptor("image_variance", "2d-translation")
+    theta = np.array([6.0, -9.0])
+    ref = orc.objective(ev, theta, "2d-translation", size, cost="image_variance", sigma=0)
+    for det in (False, True, False, True):
+        h.set_deterministic(det)
+        res, grad = h.evaluate(desc, theta)
+        assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"]), det
+        assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL, det
+    iwe = h.iwe(theta, "2d-translation").cpu().numpy()  # cmax_iwe in deterministic mode
+    assert rel_max(iwe, ref["iwes"]["iwe"]) <= TOL
