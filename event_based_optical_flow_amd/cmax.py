@@ -7,6 +7,7 @@ materialising warped events.  `ContrastObjective` exposes it as a differentiable
 `loss = objective(motion)` for `scipy_autograd.minimize` / `torch.autograd.grad`.
 """
 import ctypes
+import logging
 from typing import Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -17,6 +18,8 @@ from . import functional as F
 from ._lib import CmaxObjective, check
 from .array_types import to_device_tensor
 from .costs.hybrid import combine
+
+logger = logging.getLogger(__name__)
 
 _COST_TABLE = {
     # name: (cost code, normalized, [(direction, multiplier), ...])  -- which IWEs get_arg_for_cost builds
@@ -107,7 +110,18 @@ class CMaxHandle:
                                         float(tmin) if have else 0.0, float(tmax) if have else 0.0, int(time_bin),
                                         F._stream()))
         self.time_bin = int(time_bin)
+        dropped = self.batch_info()["dropped"]
+        if dropped:
+            logger.warning(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events: source pixel outside the "
+                           f"{self.image_size[0]} x {self.image_size[1]} sensor (or NaN); the fused path cannot keep them")
         return self
+
+    def batch_info(self) -> Dict[str, int]:
+        """{"packed", "dropped", "fractional", "owned_groups"} of the last set_events (cmax_batch_info)."""
+        n, d = ctypes.c_int64(0), ctypes.c_int64(0)
+        f, o = ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.cmax_batch_info(self._h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(f), ctypes.byref(o)))
+        return {"packed": n.value, "dropped": d.value, "fractional": bool(f.value), "owned_groups": bool(o.value)}
 
     def set_time_bins(self, time_bin: int):
         check(self._lib.cmax_set_time_bins(self._h, int(time_bin), F._stream()))

@@ -106,6 +106,7 @@ struct cmax_handle_s {
     int H = 0, W = 0, ph = 0, pw = 0, Hp = 0, Wp = 0;
     int device = 0;
     int64_t n = 0, cap = 0;
+    int64_t n_dropped = 0;  // events of the last batch whose source pixel was off the sensor (or NaN): not packed
     bool has_frac = false;
     int n_time_bin = 0;
     // packed, sorted events
@@ -165,6 +166,7 @@ struct cmax_handle_s {
     int search_cap = 0;
     int64_t bytes = 0;
     uint64_t generation = 0;  // bumped by set_events / set_time_bins (device pointers and the work list change)
+    uint64_t generation_counted = ~(uint64_t)0;
     // optional per-kernel-class timing with HIP events (cmax_set_profiling)
     bool profiling = false;
     int prof_repeat = 1;  // > 1: every hot launch is issued this many times inside its event bracket (timing only)
@@ -1508,6 +1510,10 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         std::memcpy(rb->tmm, h->hp_read + off_tmm, 2 * sizeof(double));
         h->has_frac = rb->flags[0] != 0;
         h->n = rb->n_in - rb->flags[1];
+        if (h->generation_counted != h->generation) {  // a new batch (re-binning keeps the count of cmax_set_events)
+            h->n_dropped = rb->flags[1];
+            h->generation_counted = h->generation;
+        }
         int64_t active = 0;  // source pixels that hold events (un-binned order)
         if (want_active)
             for (int k = 0; k < ntiles; ++k) active += h->hp_read[off_active + k];
@@ -1767,7 +1773,9 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     hipStream_t s = (hipStream_t)stream;
     h->orig_valid = false;
     h->n = 0;
+    h->n_dropped = 0;
     ++h->generation;
+    h->generation_counted = ~(uint64_t)0;
     if (n > h->cap) {
         // the old buffers may still be in use by work queued on the stream
         CMAX_CHECK_HIP(hipStreamSynchronize(s));
@@ -2478,6 +2486,15 @@ int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h,
     hipLaunchKernelGGL(k_patch_search, dim3(n_patch, n_cand + 1), dim3(kSearchThreads), lds, s, a, h->search_range, n_cand,
                        (const float2 *)cand, (float)(h->tmax_host - h->tmin_host), (float)sigma, radius, gm_out);
     CMAX_CHECK_LAUNCH();
+    return 0;
+}
+
+int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int *has_fractional, int *owned_groups) {
+    CMAX_REQUIRE(h != nullptr, "batch_info");
+    if (n_packed) *n_packed = h->n;
+    if (n_dropped) *n_dropped = h->n_dropped;
+    if (has_fractional) *has_fractional = h->has_frac ? 1 : 0;
+    if (owned_groups) *owned_groups = h->owned ? 1 : 0;
     return 0;
 }
 

@@ -47,16 +47,20 @@ def search_box(m0: np.ndarray, abs_range: float = 10.0):
 
 
 def pyramid_expand(motion: np.ndarray) -> np.ndarray:
-    """[2,h,w] -> [2,2h,2w]: order-1 up-sampling then Gaussian smoothing (sigma = 2*upscale/6)."""
-    out = np.stack([ndi.zoom(c, 2, order=1, mode="reflect", grid_mode=True) for c in motion])
+    """[2,h,w] -> [2,2h,2w]: skimage.transform.pyramid_expand(channel_axis=0) restated on scipy.ndimage -- order-1 resize
+    (skimage's mode "reflect" is ndimage's "mirror" for the resampling step), then Gaussian smoothing with
+    sigma = 2 * upscale / 6, for which skimage hands its mode string to ndimage unchanged ("reflect").  skimage is not
+    in this image: the mapping follows its source as recalled, unpinned."""
+    out = np.stack([ndi.zoom(c, 2, order=1, mode="mirror", grid_mode=True) for c in motion])
     return np.stack([ndi.gaussian_filter(c, 2 * 2 / 6.0, mode="reflect") for c in out])
 
 
 def pyramid_reduce(motion: np.ndarray) -> np.ndarray:
-    """[2,h,w] -> [2,ceil(h/2),ceil(w/2)]: Gaussian smoothing (sigma = 2*downscale/6) then order-1 down-sampling."""
+    """[2,h,w] -> [2,ceil(h/2),ceil(w/2)]: Gaussian smoothing (sigma = 2 * downscale / 6, ndimage "reflect") then order-1
+    down-sampling (ndimage "mirror"), as skimage.transform.pyramid_reduce does."""
     sm = np.stack([ndi.gaussian_filter(c, 2 * 2 / 6.0, mode="reflect") for c in motion])
     shape = (int(np.ceil(motion.shape[1] / 2)), int(np.ceil(motion.shape[2] / 2)))
-    return np.stack([ndi.zoom(c, (shape[0] / c.shape[0], shape[1] / c.shape[1]), order=1, mode="reflect", grid_mode=True)
+    return np.stack([ndi.zoom(c, (shape[0] / c.shape[0], shape[1] / c.shape[1]), order=1, mode="mirror", grid_mode=True)
                      for c in sm])
 
 
@@ -192,6 +196,11 @@ class PyramidalPatchContrastMaximization:
         m0 = np.asarray(motion0, dtype=np.float64).reshape(2, -1)  # [2, n_patch]
         n_patch = m0.shape[1]
         size = self.scaled_patch_size[s]
+        if self.padding:
+            # the reference's small-patch imager is padded by outer_padding (EventImageConverter(scaled_size, outer_padding));
+            # cmax_patch_search votes into the un-padded patch image.  No shipped YAML uses a padding: refuse rather than
+            # score the candidates on a different image
+            raise NotImplementedError("per-patch re-initialisation with outer_padding != 0 is not built")
         if 2 * size[0] * size[1] * 4 > 64 * 1024 - 256:  # patch image beyond the workgroup's LDS (scale 1 of a large crop)
             logger.info(f"Scale {s}: patch {size} too large for the batched search, keeping the expanded motion")
             return m0.reshape(-1)
@@ -207,7 +216,9 @@ class PyramidalPatchContrastMaximization:
         cand = np.concatenate([m0.T[:, None, :], cand], axis=1)
         loss, _, count = handle.patch_search(self.patch_boxes(s), size, cand, self.iwe_config["blur_sigma"])
         loss = loss.cpu().numpy()
-        loss[~np.isfinite(loss)] = np.inf
+        # the reference turns a NaN loss into 0.0 (calculate_cost_for_small_patch / objective_initial,
+        # patch_contrast_pyramid.py:376-378, 411-414) -- under "minimize" that trial then wins; mirrored as it is
+        loss[np.isnan(loss)] = 0.0
         pick = loss.argmin(axis=1)
         m1 = cand[np.arange(n_patch), pick].T.copy()  # [2, n_patch]
         keep = count.cpu().numpy() <= 10
@@ -216,10 +227,12 @@ class PyramidalPatchContrastMaximization:
         return m1.reshape(-1)
 
     def update_coarse_from_fine(self, motion_per_scale: dict) -> dict:
+        """patch_contrast_pyramid.py:205-222: the finest motion, and below it the reduced OPTIMISED motion of the next finer
+        scale -- keys finest ... coarsest - 1, exactly the reference's (the extra key coarsest - 1 is never read)."""
         finest, coarsest = max(motion_per_scale), min(motion_per_scale)
         refined = {finest: motion_per_scale[finest]}
-        for i in range(finest, coarsest, -1):
-            refined[i - 1] = pyramid_reduce(refined[i])
+        for i in range(finest, coarsest - 1, -1):
+            refined[i - 1] = pyramid_reduce(motion_per_scale[i])
         return refined
 
     def motion_to_dense_flow(self, motion_per_scale: dict) -> np.ndarray:

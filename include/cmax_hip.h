@@ -328,6 +328,14 @@ int cmax_sizeof_objective(void);
  * contrast was evaluated on, i.e. blurred when sigma > 0) into iwe_out, on `stream`.          */
 int cmax_copy_iwe(cmax_handle_t h, int k, float *iwe_out, cmax_stream_t stream);
 
+/* What cmax_set_events made of the last batch: events packed; events DROPPED because their source pixel lies
+ * outside the sensor or is NaN (the fused path indexes the flow field and the source tiles with it, so such
+ * events cannot be kept -- the leaf operators cmax_warp_events + cmax_vote have no such filter and follow the
+ * reference, which lets a 2-DoF event from outside the sensor vote if it warps into the padded image); whether
+ * any source coordinate is fractional; whether the work list gives every group to one segment (owned groups:
+ * single-reference dense / voxel gradients are then stored, not added).  Any pointer may be NULL.            */
+int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int *has_fractional, int *owned_groups);
+
 /* Introspection for tests / bench: number of packed events, HBM bytes held by the handle.     */
 int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_bytes);
 

@@ -424,3 +424,29 @@ def test_dense_with_padding_and_fractional_sources():
     assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_max(grads[0], ref["grad"]) <= TOL
+
+
+def test_dropped_events_are_counted_and_reported(caplog):
+    """cmax_set_events drops events whose source pixel is off the sensor or NaN; the count is exposed
+    (cmax_batch_info) and logged.  The surviving events give the oracle's result for the same survivors."""
+    import logging
+
+    size, n = (48, 64), 20_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=91)
+    ev[5, 0] = -3.0
+    ev[77, 1] = size[1] + 2.0
+    ev[1234, 0] = np.nan
+    with caplog.at_level(logging.WARNING):
+        h = E.CMaxHandle(size).set_events(ev)
+    info = h.batch_info()
+    assert info["dropped"] == 3 and info["packed"] == n - 3 and not info["fractional"]
+    assert any("dropped 3" in r.message for r in caplog.records)
+    keep = np.ones(n, dtype=bool)
+    keep[[5, 77, 1234]] = False
+    theta = np.array([4.0, -6.0])
+    res, grad = h.evaluate(E.make_descriptor("image_variance", "2d-translation"), theta)
+    ref = orc.objective(ev[keep], theta, "2d-translation", size, cost="image_variance", sigma=0)
+    # t_min / t_max of the batch are taken over ALL events (dropped ones included), like the reference's warp would
+    assert abs(res[0].item() - ref["loss"]) <= 1e-3 * abs(ref["loss"])
+    h.set_events(ev[keep])
+    assert h.batch_info()["dropped"] == 0

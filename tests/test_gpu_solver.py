@@ -343,7 +343,8 @@ def test_pyramid_solver_end_to_end(time_aware):
     np.random.seed(46)
     slv = solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, slv_cfg, opt_cfg, {}, None)
     best = slv.optimize(ev)
-    assert sorted(best) == [1, 2, 3] and best[3].shape == (2, 8, 8) and best[1].shape == (2, 2, 2)
+    # the reference's feedback dict: finest ... coarsest - 1 (update_coarse_from_fine, patch_contrast_pyramid.py:205-222)
+    assert sorted(best) == [0, 1, 2, 3] and best[3].shape == (2, 8, 8) and best[1].shape == (2, 2, 2)
     flow = slv.motion_to_dense_flow(best) * t_scale  # pixel displacement over the batch
     mask = np.zeros((H, W), bool)
     mask[x.astype(int), y.astype(int)] = True

@@ -230,3 +230,27 @@ def test_patch_boxes_and_search_box_follow_the_reference(golden):
     lo, hi = search_box(np.array([100.0, -100.0, 2.0, 0.0]))
     np.testing.assert_allclose(lo, [80.0, -120.0, -8.0, -10.0])
     np.testing.assert_allclose(hi, [120.0, -80.0, 12.0, 10.0])
+
+
+def test_pyramid_ops_and_feedback_keys():
+    """pyramid_expand / pyramid_reduce (skimage restated on scipy.ndimage) keep constants and shapes; the coarse-from-fine
+    feedback returns the reference's key set finest ... coarsest - 1 (src/solver/patch_contrast_pyramid.py:205-222) and
+    reduces the OPTIMISED motion of the next finer scale."""
+    from event_based_optical_flow_amd.solver import pyramid as P
+
+    m = np.full((2, 4, 6), 3.5)
+    up, down = P.pyramid_expand(m), P.pyramid_reduce(m)
+    assert up.shape == (2, 8, 12) and down.shape == (2, 2, 3)
+    np.testing.assert_allclose(up, 3.5, rtol=1e-12)
+    np.testing.assert_allclose(down, 3.5, rtol=1e-12)
+    ramp = np.stack([np.tile(np.arange(6.0), (4, 1)), np.tile(np.arange(4.0)[:, None], (1, 6))])
+    up = P.pyramid_expand(ramp)
+    assert np.all(np.diff(up[0], axis=1) >= -1e-12) and np.all(np.diff(up[1], axis=0) >= -1e-12)  # monotone stays monotone
+    motions = {1: np.random.default_rng(0).normal(size=(2, 2, 2)), 2: np.random.default_rng(1).normal(size=(2, 4, 4)),
+               3: np.random.default_rng(2).normal(size=(2, 8, 8))}
+    fb = P.PyramidalPatchContrastMaximization.update_coarse_from_fine(None, motions)
+    assert sorted(fb) == [0, 1, 2, 3]
+    np.testing.assert_array_equal(fb[3], motions[3])
+    np.testing.assert_allclose(fb[2], P.pyramid_reduce(motions[3]))
+    np.testing.assert_allclose(fb[1], P.pyramid_reduce(motions[2]))  # the optimised scale-2 motion, not the reduced feedback
+    np.testing.assert_allclose(fb[0], P.pyramid_reduce(motions[1]))
