@@ -525,7 +525,11 @@ __device__ __forceinline__ void seg_scan64(int head, float &vx, float &vy, int l
 constexpr int kStatBlocksMax = 512;
 constexpr int kStatSlots = 5;  // reference times 0..3, slot 4 = un-warped image
 constexpr int kStatSub = 32;   // sub-accumulators per slot
-constexpr int kStatStride = kStatSub * 2;
+// Every sub-accumulator sits on its OWN 128-byte line: atomics to one cache line serialise in the L2 atomic unit whatever
+// their address inside it (~7 ns each).  Packed 16 bytes apart, the up to 32 sub-accumulators of a slot shared 1-4 lines, and
+// the 363 workgroups of a 260 x 346 image kernel spent 5 of their 9.8 us queueing on ONE line (profiles/r02_ablation.txt).
+constexpr int kSubStride = 16;  // doubles between sub-accumulators
+constexpr int kStatStride = kStatSub * kSubStride;
 
 struct ObjParams {
     int cost, normalized, minimize, negate, omit, n_ref;
@@ -558,8 +562,8 @@ __device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int sl
         const int lane = threadIdx.x & (kWave - 1);
         double a0 = 0.0, a1 = 0.0;
         if (lane < nsub) {
-            a0 = stat[slot * kStatStride + 2 * lane];
-            a1 = stat[slot * kStatStride + 2 * lane + 1];
+            a0 = stat[slot * kStatStride + kSubStride * lane];
+            a1 = stat[slot * kStatStride + kSubStride * lane + 1];
         }
         a0 = wave_sum_lane63(a0);
         a1 = wave_sum_lane63(a1);
@@ -570,8 +574,8 @@ __device__ __forceinline__ void stat_sum(const double *__restrict__ stat, int sl
     acc[0] = 0.0;
     acc[1] = 0.0;
     for (int u = 0; u < nsub; ++u) {
-        acc[0] += stat[slot * kStatStride + 2 * u];
-        acc[1] += stat[slot * kStatStride + 2 * u + 1];
+        acc[0] += stat[slot * kStatStride + kSubStride * u];
+        acc[1] += stat[slot * kStatStride + kSubStride * u + 1];
     }
 }
 
@@ -631,8 +635,6 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
     if (zero_img) zero_img += blockIdx.y * bs;
     // the flow-gradient buffer K3 accumulates into is cleared here (a hipMemsetAsync node costs 4-5 us)
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
-    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
-    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     const unsigned stride = gridDim.x * 256u;
@@ -665,9 +667,13 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
             }
         }
     }
+    // The clearing stores go out AFTER the image loads have been consumed: vmcnt retires in issue order, so a
+    // write-through store issued first sits on the critical path of every load behind it (k_stats 6.2 -> see profiles)
+    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) {
-        double *a = stat_slot + 2 * (blockIdx.x % nsub);
+        double *a = stat_slot + kSubStride * (blockIdx.x % nsub);
         atomic_add(&a[0], v[0]);
         if (COST == CMAX_COST_VARIANCE) atomic_add(&a[1], v[1]);
     }
@@ -688,8 +694,6 @@ k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsu
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
-    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
-    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
     double v[2] = {0.0, 0.0};
@@ -704,9 +708,11 @@ k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsu
             v[1] += (double)b * (double)b;
         }
     }
+    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) {
-        double *a = stat_slot + 2 * (blockIdx.x % nsub);
+        double *a = stat_slot + kSubStride * (blockIdx.x % nsub);
         atomic_add(&a[0], v[0]);
         atomic_add(&a[1], v[1]);
     }
@@ -723,8 +729,6 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
     float *__restrict__ G = ia.G[blockIdx.y];
     double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
-    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
-    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const int tiles_w = (W + kGmTileW - 1) / kGmTileW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int r0 = tr * kGmTileH - 2, c0 = tc * kGmTileW - 2;
@@ -734,6 +738,8 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
         tile[a][b] = ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? img[(int64_t)r * W + c] : 0.f;
     }
     __syncthreads();
+    if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const int i0 = omit ? 1 : 0;
     const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0);
     const int la = threadIdx.x / kGmTileW, lb = threadIdx.x - la * kGmTileW;  // pixel of this thread inside the tile
@@ -768,7 +774,7 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
         if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) v[0] = (double)(gx[1][1] * gx[1][1] + gy[1][1] * gy[1][1]);
     }
     block_sum<2>(v, smem);
-    if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
+    if (threadIdx.x == 0) atomic_add(&stat_slot[kSubStride * (blockIdx.x % nsub)], v[0]);
 }
 
 // Blurred gradient-magnitude cost (the shipped YAML cost), whole image side of one reference time in ONE kernel:
@@ -793,8 +799,6 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
     __shared__ float t_gy[TH + 4][TW + 4 + 1];
     __shared__ float t_g[TH + 2][TW + 2 + 1];   // G', halo 1, zero outside the image
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
-    zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);
-    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const int tiles_w = (W + TW - 1) / TW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
@@ -805,6 +809,8 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
         t_i[a][b] = in_img(r, c) ? img[(int64_t)r * W + c] : 0.f;
     }
     __syncthreads();
+    zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     for (int q = threadIdx.x; q < (TH + 6) * (TW + 6); q += 256) {
         const int a = q / (TW + 6), b = q - a * (TW + 6), r = R0 - 3 + a, c = C0 - 3 + b;
         float v = 0.f;
@@ -856,7 +862,7 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
         }
     }
     block_sum<2>(v, smem);
-    if (threadIdx.x == 0) atomic_add(&stat_slot[2 * (blockIdx.x % nsub)], v[0]);
+    if (threadIdx.x == 0) atomic_add(&stat_slot[kSubStride * (blockIdx.x % nsub)], v[0]);
 }
 
 __global__ void k_finalize(ObjParams op, const double *__restrict__ stat, double *__restrict__ result) {
@@ -968,7 +974,7 @@ k_stats_tan(const float *__restrict__ img, const float *__restrict__ dimg, int H
     }
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) {
-        double *a = st + 2 * (blockIdx.x % nsub);
+        double *a = st + kSubStride * (blockIdx.x % nsub);
         atomic_add(&a[0], v[0]);
         if (COST == CMAX_COST_VARIANCE) atomic_add(&a[1], v[1]);
     }
@@ -989,8 +995,8 @@ k_gimage_tan(const float *__restrict__ img, const float *__restrict__ dimg, ObjP
     double acc[2], tacc[2] = {0.0, 0.0};
     stat_sum(stat, k, op.nsub, acc);
     for (int u = 0; u < op.nsub; ++u) {
-        tacc[0] += st[2 * u];
-        tacc[1] += st[2 * u + 1];
+        tacc[0] += st[kSubStride * u];
+        tacc[1] += st[kSubStride * u + 1];
     }
     double mu = 0.0;
     const double v = contrast_value(COST, acc, npix, &mu);
@@ -1425,8 +1431,12 @@ static int stat_blocks(const cmax_handle_s *h) {
 // statistics of `img` -> stat[slot] (accumulators zeroed by the K1 launch); optionally zero `zero_img`
 static int stat_subs(const cmax_handle_s *h) {
     if (h->deterministic) return kStatSub;
-    int n = stat_blocks(h) / 12;  // ~12 same-address atomics per accumulator
-    return n < 4 ? 4 : (n > kStatSub ? kStatSub : n);
+    // one 128-byte line per sub-accumulator: every consumer (each K3 workgroup) gathers nsub lines at its head, so few of
+    // them; 8 lines keep the atomics of even 1200 image-kernel workgroups at ~150 per line (cfg3 K3 21.1 us with 25 lines,
+    // 18.7 with 8; the image kernel 5.6 either way)
+    int n = stat_blocks(h) / 12;
+    if (const char *e = getenv("CMAX_NSUB")) return atoi(e);
+    return n < 4 ? 4 : (n > 8 ? 8 : n);
 }
 
 // zero_extra: optional buffer of n_extra floats (16-byte aligned, n_extra % 4 == 0) cleared by the same launch
