@@ -171,6 +171,11 @@ struct cmax_handle_s {
     bool profiling = false;
     int prof_repeat = 1;  // > 1: every hot launch is issued this many times inside its event bracket (timing only)
     std::vector<hipEvent_t> prof_ev[CMAX_PROF_CLASSES];  // class -> [start0, stop0, start1, stop1, ...]
+    // 2-DoF tangent images (k_vote_tan2): [2 buffers][4 reference times][I: Hp Wp | E0: (Hp + 1) Wp | F1: Hp (Wp + 1)]
+    float *tan = nullptr;
+    int tan_cur = 0;
+    unsigned tan_zero_mask[2] = {0u, 0u};  // bit k: planes of reference time k of buffer b are zero
+    double *d_tanpart = nullptr;           // [4][kTanBlocks][6] partial sums of k_tan_stats_var
     // time-sliced multi-GPU evaluation: this rank's RCCL communicator (cmax_comm_init), or null
     cmax::Comm *comm = nullptr;
     // deterministic mode (cmax_set_deterministic): every accumulation that depends on the order of events, workgroups or
@@ -863,6 +868,76 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
     }
     block_sum<2>(v, smem);
     if (threadIdx.x == 0) atomic_add(&stat_slot[kSubStride * (blockIdx.x % nsub)], v[0]);
+}
+
+// 2-DoF, plain variance, tangent images (k_vote_tan2): everything the loss and the gradient need, in image space.
+//   With m = 1_Omega (zero outside the image) and G = c (I - mu) m:
+//     dL/dtheta0 = sum_q E0[q] (G~[q + (1,0)] - G~[q]) = c (S1x - mu S2x),
+//       S1x = sum_q E0[q] (m I)[q + (1,0)] - (m I)[q],   S2x = sum_q E0[q] (m[q + (1,0)] - m[q]),   likewise S1y, S2y with F1
+//   -- the six sums k_finish_deferred turns into loss, chain factors and gradient (the same quantities the deferred K3
+//   gathers per event).  grid (kTanBlocks, n_ref); per-block partials [k][block][6]; clears the planes of the next evaluation.
+constexpr int kTanBlocks = 128;
+__global__ void __launch_bounds__(256)
+k_tan_stats_var(const float *__restrict__ T, float *__restrict__ Tnext, int64_t tstride, int Hp, int Wp, int omit, int normalize,
+                const double *__restrict__ tmm, double *__restrict__ part) {
+    __shared__ double smem[6 * 4];
+    const int k = blockIdx.y;
+    const float *__restrict__ I = T + k * tstride;
+    const float *__restrict__ E0 = I + (int64_t)Hp * Wp;        // row r of the image is stored row r + 1
+    const float *__restrict__ F1 = E0 + (int64_t)(Hp + 1) * Wp;  // column c is stored column c + 1, row stride Wp + 1
+    const float ts = normalize ? 1.f : (float)(tmm[1] - tmm[0]);  // the votes carry dt / period
+    const int i0 = omit ? 1 : 0;
+    const int npix = Hp * Wp;
+    auto mask = [&](int r, int c) -> bool { return r >= i0 && r < Hp - i0 && c >= i0 && c < Wp - i0; };
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const int r = p / Wp, c = p - r * Wp;
+        const bool m = mask(r, c), md = r + 1 < Hp && mask(r + 1, c), mr = c + 1 < Wp && mask(r, c + 1);
+        const float x = m ? I[p] : 0.f, xd = md ? I[p + Wp] : 0.f, xr = mr ? I[p + 1] : 0.f;
+        const float e = E0[(int64_t)(r + 1) * Wp + c] * ts, f = F1[(int64_t)r * (Wp + 1) + c + 1] * ts;
+        v[0] += (double)(e * (xd - x));
+        v[1] += (double)(f * (xr - x));
+        v[2] += (double)(e * ((md ? 1.f : 0.f) - (m ? 1.f : 0.f)));
+        v[3] += (double)(f * ((mr ? 1.f : 0.f) - (m ? 1.f : 0.f)));
+        if (r == 0) {  // votes whose upper corner lies one row above the image
+            const float eu = E0[c] * ts;
+            v[0] += (double)(eu * x);
+            v[2] += (double)(eu * (m ? 1.f : 0.f));
+        }
+        if (c == 0) {  // ... one column left of it
+            const float fl = F1[(int64_t)r * (Wp + 1)] * ts;
+            v[1] += (double)(fl * x);
+            v[3] += (double)(fl * (m ? 1.f : 0.f));
+        }
+        v[4] += (double)x;
+        v[5] += (double)x * (double)x;
+    }
+    if (Tnext) zero_fill_sc1(Tnext + k * tstride, tstride, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+    // the four gradient sums go over the wave in fp32 (DPP adds; their terms carry fp32 rounding already) and in fp64 across
+    // waves and workgroups, the two image sums stay fp64 throughout -- as in the deferred K3 (a block_sum of six doubles is
+    // 36 dependent v_add_f64 behind 72 DPP moves)
+    float *s_f = reinterpret_cast<float *>(smem + 2 * 4);  // [4][4] floats behind the doubles of block_sum<2>
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float w = (float)v[q];
+        w += dpp_f<kDppRowShr1>(w);
+        w += dpp_f<kDppRowShr2>(w);
+        w += dpp_f<kDppRowShr4>(w);
+        w += dpp_f<kDppRowShr8>(w);
+        w += dpp_f<kDppRowBcast15>(w);
+        w += dpp_f<kDppRowBcast31>(w);
+        if (lane == kWave - 1) s_f[q * 4 + wave] = w;
+    }
+    double im[2] = {v[4], v[5]};
+    block_sum<2>(im, smem);  // (its barriers also publish s_f)
+    if (threadIdx.x == 0) {
+        double *o = part + ((int64_t)k * gridDim.x + blockIdx.x) * 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (double)s_f[q * 4] + (double)s_f[q * 4 + 1] + (double)s_f[q * 4 + 2] + (double)s_f[q * 4 + 3];
+        o[4] = im[0];
+        o[5] = im[1];
+    }
 }
 
 __global__ void k_finalize(ObjParams op, const double *__restrict__ stat, double *__restrict__ result) {
@@ -1735,6 +1810,8 @@ int cmax_destroy(cmax_handle_t h) {
     if (!h) return 0;
     comm_destroy(h->comm);
     h->comm = nullptr;
+    dev_free(&h->tan);
+    dev_free(&h->d_tanpart);
     dev_free(&h->img64);
     dev_free(&h->d_imax);
     dev_free(&h->g64);
@@ -2113,10 +2190,89 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const floa
     return objective_finish(h, d, motion, images, n_images, nullptr, result, grad, (hipStream_t)stream, false);
 }
 
+// 2-DoF, plain variance: K1T (image + two tangent images) -> [ONE all-reduce] -> k_tan_stats_var -> k_finish_deferred.
+// No pass over the events for the gradient, and across GPUs no second exchange: after the all-reduce every rank holds
+// the whole batch's three images and finishes loss and gradient on its own.
+static bool tan2_applicable(const cmax_handle_s *h, const cmax_objective_t *d, const void *grad, bool dist) {
+    static const int force = getenv("CMAX_TAN2") ? atoi(getenv("CMAX_TAN2")) : -1;  // tuning: 1 = also on one GPU, 0 = never
+    if (force == 0 || h->deterministic || !grad) return false;
+    if (d->model != CMAX_MODEL_2DOF || d->cost != CMAX_COST_VARIANCE || d->sigma > 0) return false;
+    if (d->normalized && !(h->orig_valid && h->orig_sigma == d->sigma && h->orig_cost == d->cost && h->orig_omit == d->omit_boundary))
+        return false;  // the first evaluation of a batch builds the un-warped image's statistics on the standard path
+    return dist || force == 1;
+}
+
+static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s,
+                               cmax::Comm *comm) {
+    const int Hp = h->Hp, Wp = h->Wp, nr = d->n_ref;
+    const int64_t tsize = (int64_t)3 * Hp * Wp + Hp + Wp;
+    const int64_t tstride = (tsize + 3) & ~(int64_t)3;  // 16-byte aligned planes: the clearing stores are 16 bytes wide
+    int rc = 0;
+    if (!h->tan) {
+        rc = dev_alloc(h, &h->tan, 2 * 4 * tstride);
+        if (!rc) rc = dev_alloc(h, &h->d_tanpart, 4 * kTanBlocks * 6);
+        if (rc) return rc;
+        h->tan_zero_mask[0] = h->tan_zero_mask[1] = 0u;
+    }
+    float *cur = h->tan + (int64_t)h->tan_cur * 4 * tstride, *nxt = h->tan + (int64_t)(h->tan_cur ^ 1) * 4 * tstride;
+    RefArgs ra = {};
+    for (int k = 0; k < nr; ++k) {
+        if (!((h->tan_zero_mask[h->tan_cur] >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(cur + k * tstride, 0, (size_t)tstride * sizeof(float), s));
+        ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.img[k] = cur + k * tstride;
+    }
+    const unsigned used = (1u << nr) - 1u;
+    h->tan_zero_mask[h->tan_cur] &= ~used;
+    const WarpParams wp = warp_params(h, motion, 0, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
+    if (h->n > 0) {
+        const EvView ev = ev_view(h);
+        const dim3 grid(8 * ((h->nseg + 7) / 8), nr);
+        ProfScope prof(h, kProfVote, s);
+        for (int rep = 0; rep < h->prof_repeat; ++rep) {
+            if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan2<true>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
+            else hipLaunchKernelGGL((t256::k_vote_tan2<false>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
+        }
+        CMAX_CHECK_LAUNCH();
+    }
+    if (comm) {  // the ONE exchange of a 2-DoF evaluation: all planes of all reference times are contiguous
+        ProfScope prof(h, kProfComm, s);
+        rc = comm_allreduce(comm, cur, (size_t)nr * tstride, kCommF32, kCommSum, s);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < nr; ++k) h->last_iwe[k] = cur + k * tstride;  // the raw image is the first plane
+    {
+        ProfScope prof(h, kProfStats, s);
+        for (int rep = 0; rep < h->prof_repeat; ++rep)
+            hipLaunchKernelGGL(k_tan_stats_var, dim3(kTanBlocks, nr), dim3(256), 0, s, cur, nxt, tstride, Hp, Wp, d->omit_boundary, d->normalize_t,
+                               h->d_tmm, h->d_tanpart);
+        CMAX_CHECK_LAUNCH();
+    }
+    h->tan_zero_mask[h->tan_cur ^ 1] |= used;
+    h->tan_cur ^= 1;
+    ObjParams op;
+    op.cost = d->cost;
+    op.normalized = d->normalized;
+    op.minimize = d->minimize;
+    op.negate = d->negate;
+    op.omit = d->omit_boundary;
+    op.n_ref = d->n_ref;
+    for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
+    op.H = Hp;
+    op.W = Wp;
+    op.nsub = stat_subs(h);
+    {
+        ProfScope prof(h, kProfFinish, s);
+        hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_tanpart, kTanBlocks, result, (double *)grad);
+        CMAX_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 // vote -> [all-reduce of the images] -> finish -> [all-reduce of the gradient], all on the handle's double-buffered images
 static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s,
                           cmax::Comm *comm) {
     const bool dist = comm != nullptr;  // also a 1-rank communicator: the same enqueue sequence, RCCL included
+    if ((h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
     const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
     const size_t gbytes = d->model == CMAX_MODEL_2DOF ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
     // empty batch: loss 0, zero gradient (patch_contrast_base.py:253-255).  A time slice may be empty while the batch is not.

@@ -268,6 +268,10 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, co
  *   un-warped image in ONE call) -> contrast statistics + loss (redundantly, identical on every rank)
  *   + K3 gather of this slice's events -> all-reduce(sum) of the gradient (fp64 [2] | fp32 [2,H,W] |
  *   fp32 [T,2,H,W]).  No other exchange; no host synchronisation.
+ *   2-DoF with the plain variance cost (BASELINE's headline) needs ONE exchange: K1 votes the image and its two
+ *   tangent images dI/dtheta (two more votes per event), one all-reduce carries the three of them, and every rank
+ *   finishes loss and gradient <dL/dI, dI/dtheta> in image space -- no pass over the events for the gradient and no
+ *   16-byte all-reduce whose cost is pure latency.
  * RCCL is bound at run time (the librccl already in the process, i.e. torch's, else ROCm's); a handle
  * without a communicator -- or with nranks == 1 -- never touches it.
  * ============================================================================================= */

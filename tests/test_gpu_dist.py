@@ -163,3 +163,51 @@ def test_bench_two_ranks_on_one_gpu_self_launched():
     assert out["n_gpus"] == 2 and out["config"]["events_per_gpu"] == 1_000_000
     assert out["config"]["collectives"].startswith("torch.distributed")
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+TAN_CASES = [
+    # cost, theta, pad, fractional sources, normalize_t, warp direction
+    ("image_variance", (9.0, -6.0), 0, False, True, "first"),
+    ("image_variance", (9.0, -6.0), 3, True, True, "middle"),
+    ("image_variance", (0.4, -0.2), 0, False, False, "last"),       # dt in the events' own unit (period 2.5): displacement ~1 px
+    ("image_variance", (40.0, 35.0), 2, False, True, "after"),       # |dt| up to 2: the 14.18 fixed-point range of the tangent planes
+    ("image_variance", (150.0, -140.0), 0, False, True, "first"),   # windows beyond three LDS planes: the tested global path
+    ("normalized_image_variance", (9.0, -6.0), 0, False, True, "first"),
+    ("multi_focal_normalized_image_variance", (12.0, 5.0), 1, False, True, "first"),
+]
+
+
+@pytest.mark.parametrize("cost,theta,pad,frac,normalize_t,direction", TAN_CASES,
+                         ids=[f"{c[0]}-{i}" for i, c in enumerate(TAN_CASES)])
+def test_two_dof_single_exchange_path(world1_nccl, cost, theta, pad, frac, normalize_t, direction):
+    """2-DoF + plain variance under a communicator: K1T votes the image and its two tangent images, ONE all-reduce, loss and
+    gradient in image space (k_vote_tan2 / k_tan_stats_var) -- against the oracle and against the single-GPU path (K1 + K3)."""
+    size, n = (96, 128), 150_000
+    rng = np.random.default_rng(15)
+    t0, t1 = (1.0, 3.5) if not normalize_t else (0.0, 0.05)
+    if normalize_t:
+        ev = E.utils.generate_structured_events(n, size[0], size[1], (theta[0] * 0.9, theta[1] * 0.9), n_dots=400, tmin=t0, tmax=t1, seed=15)
+    else:
+        ev = E.utils.generate_events(n, size[0], size[1], t0, t1, seed=15)
+    if frac:
+        ev[:, 0] = np.clip(ev[:, 0] + rng.uniform(0, 0.99, n), 0, size[0] - 1e-3)
+        ev[:, 1] = np.clip(ev[:, 1] + rng.uniform(0, 0.99, n), 0, size[1] - 1e-3)
+    theta = np.array(theta)
+    desc = E.make_descriptor(cost, "2d-translation", normalize_t=normalize_t, warp_direction=direction)
+    h = E.CMaxHandle(size, pad).set_events(ev)
+    res, grad = h.evaluate(desc, theta)  # standard path (also caches the un-warped image's statistics)
+    h.comm_init(force_rccl=True)
+    for _ in range(3):
+        res_d, grad_d = h.evaluate_dist(desc, theta)
+    iwe_d = h.last_iwe(0).cpu().numpy()
+    torch.cuda.synchronize()
+    assert abs(res_d[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())
+    assert rel_max(grad_d.cpu().numpy(), grad.cpu().numpy()) <= 2e-5
+    if cost == "image_variance":  # the oracle's objective() takes one direction for single-reference costs
+        warped, _ = orc.warp_event(ev, theta, "2d-translation", direction, size, normalize_t=normalize_t)
+        iwe_ref = orc.create_iwe(warped, size, outer_padding=pad, sigma=0)
+        assert rel_max(iwe_d, iwe_ref) <= TOL
+    if direction == "first" and normalize_t:
+        ref = orc.objective(ev, theta, "2d-translation", size, cost=cost, sigma=0, outer_padding=pad)
+        assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+        assert rel_max(grad_d.cpu().numpy(), ref["grad"]) <= TOL
