@@ -43,6 +43,12 @@
 #include "cmax_search_kernels.h"
 #include "cmax_sort_kernels.h"
 
+// Environment knobs (tuning experiments and A/B tests only; none changes results):
+//   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
+//   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
+//   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
+//   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
+//   CMAX_PLAN_GRAPHS=1   replay the patch plan from captured hipGraphs (cmax_solver.hip)
 namespace cmax {
 
 constexpr int kSparseSegment = 512;  // voxel K3: segments below this many events add straight to memory (no LDS accumulators)
@@ -1510,7 +1516,8 @@ static int stat_subs(const cmax_handle_s *h) {
     // them; 8 lines keep the atomics of even 1200 image-kernel workgroups at ~150 per line (cfg3 K3 21.1 us with 25 lines,
     // 18.7 with 8; the image kernel 5.6 either way)
     int n = stat_blocks(h) / 12;
-    if (const char *e = getenv("CMAX_NSUB")) return atoi(e);
+    static const int forced = getenv("CMAX_NSUB") ? atoi(getenv("CMAX_NSUB")) : 0;  // tuning only
+    if (forced > 0) return forced < kStatSub ? forced : kStatSub;
     return n < 4 ? 4 : (n > 8 ? 8 : n);
 }
 
@@ -1930,6 +1937,22 @@ int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mod
     return blur_image(h, sigma, raw, iwe_out, &img, s);
 }
 
+// the objective descriptor as the kernels see it
+static ObjParams obj_params(const cmax_handle_s *h, const cmax_objective_t *d) {
+    ObjParams op;
+    op.cost = d->cost;
+    op.normalized = d->normalized;
+    op.minimize = d->minimize;
+    op.negate = d->negate;
+    op.omit = d->omit_boundary;
+    op.n_ref = d->n_ref;
+    for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
+    op.H = h->Hp;
+    op.W = h->Wp;
+    op.nsub = stat_subs(h);
+    return op;
+}
+
 static int check_objective_args(cmax_handle_t h, const cmax_objective_t *d, const float *motion) {
     CMAX_REQUIRE(h && d && motion, "objective: null pointer");
     CMAX_REQUIRE(d->model >= CMAX_MODEL_2DOF && d->model <= CMAX_MODEL_VOXEL, "objective: model");
@@ -1988,17 +2011,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
     const size_t gbytes = d->model == CMAX_MODEL_2DOF ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
 
-    ObjParams op;
-    op.cost = d->cost;
-    op.normalized = d->normalized;
-    op.minimize = d->minimize;
-    op.negate = d->negate;
-    op.omit = d->omit_boundary;
-    op.n_ref = d->n_ref;
-    for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
-    op.H = Hp;
-    op.W = Wp;
-    op.nsub = stat_subs(h);
+    const ObjParams op = obj_params(h, d);
 
     // statistics of the un-warped image (slot 4) are cached per batch
     if (d->normalized) {
@@ -2249,17 +2262,7 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
     }
     h->tan_zero_mask[h->tan_cur ^ 1] |= used;
     h->tan_cur ^= 1;
-    ObjParams op;
-    op.cost = d->cost;
-    op.normalized = d->normalized;
-    op.minimize = d->minimize;
-    op.negate = d->negate;
-    op.omit = d->omit_boundary;
-    op.n_ref = d->n_ref;
-    for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
-    op.H = Hp;
-    op.W = Wp;
-    op.nsub = stat_subs(h);
+    const ObjParams op = obj_params(h, d);
     {
         ProfScope prof(h, kProfFinish, s);
         hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_tanpart, kTanBlocks, result, (double *)grad);
@@ -2442,17 +2445,7 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *
     float *I = h->hvp_img, *Ib = I + 4 * npix, *dI = I + 8 * npix, *dIb = I + 12 * npix, *Gp = I + 16 * npix, *Gpt = I + 20 * npix;
     const int nr = d->n_ref;
 
-    ObjParams op;
-    op.cost = d->cost;
-    op.normalized = d->normalized;
-    op.minimize = d->minimize;
-    op.negate = d->negate;
-    op.omit = d->omit_boundary;
-    op.n_ref = d->n_ref;
-    for (int k = 0; k < 4; ++k) op.mult[k] = d->mult[k];
-    op.H = Hp;
-    op.W = Wp;
-    op.nsub = stat_subs(h);
+    const ObjParams op = obj_params(h, d);
     const int nsub = op.nsub;
 
     // statistics of the un-warped image (slot 4), cached per batch like in cmax_objective
