@@ -45,6 +45,7 @@
 
 // Environment knobs (tuning experiments and A/B tests only; none changes results):
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
+//   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
 //   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
@@ -1739,6 +1740,16 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
     hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, h->d_flags, stage);
     hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->cursor, h->d_flags, keys);  // cursor: free again, receives the active pixels per tile
     CMAX_CHECK_LAUNCH();
+    static const bool run_sort = !getenv("CMAX_NO_RUN_SORT");
+    if (T == 0 && run_sort) {
+        // pixel runs ordered by time: final SoA -> staging SoA, then the two swap roles (same capacities)
+        hipLaunchKernelGGL(k_run_time_sort, dim3(div_up(n_in, 256)), dim3(256), 0, s, fin, stage, h->counts + ntiles, h->d_flags);
+        CMAX_CHECK_LAUNCH();
+        std::swap(h->evp, h->evp_alt);
+        std::swap(h->rx, h->rx_alt);
+        std::swap(h->ry, h->ry_alt);
+        std::swap(h->tau64, h->tau64_alt);
+    }
     BatchReadback rb;
     rb.n_in = n_in;
     return build_segments(h, T > 0 ? 1 : 256, s, &rb);
