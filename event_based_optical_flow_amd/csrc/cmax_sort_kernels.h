@@ -268,15 +268,24 @@ k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__re
     }
 }
 
-// S4.  One workgroup per tile.  group_start: [ntiles + 1] (T == 0) or [ntiles * T + 1]; active[tile] (T == 0): source
-// pixels of this tile that hold events; tmm_keys (optional): the keyed batch extremes S1 reduced, converted to the two
-// doubles by the first workgroup (nothing in this launch reads them).
+// S4.  One workgroup per tile: LDS counting sort of the tile's bucket into the final SoA.  Key inside the tile:
+//   un-binned handle   pixel-in-tile (256 keys)
+//   binned handle      (time bin, pixel-in-tile) while T * 256 counters fit kTileKeysMax, else the time bin alone.
+// With the pixel in the key the events of a (tile, bin) group come out pixel by pixel: neighbouring lanes of the event
+// kernels then gather neighbouring voxel entries, and consecutive events of a thread mostly share (pixel, bin) -- they warp to
+// the same cell (their times differ by less than a bin), so K1 sums their votes and the voxel K3 their gradient terms in
+// registers before the LDS atomics.
+// group_start: [ntiles + 1] (T == 0) or [ntiles * T + 1]; active[tile] (T == 0): source pixels of this tile that hold
+// events; tmm_keys (optional): the keyed batch extremes S1 reduced, converted to the two doubles by the first workgroup
+// (nothing in this launch reads them).
+constexpr int kTileKeysMax = 8192;  // 32 KB of counters: (bin, pixel) keys up to T = 32
 __global__ void __launch_bounds__(kTileSortThreads)
 k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, SortOut out, int *__restrict__ group_start, int *__restrict__ active,
             const int *__restrict__ flags, unsigned long long *__restrict__ tmm_keys) {
     const bool frac = flags[0] != 0;
-    __shared__ int s_cnt[256], s_cur[256];
-    __shared__ int s_wave[256 / kWave], s_wave2[256 / kWave];
+    __shared__ int s_cnt[kTileKeysMax];  // counts, then running cursors
+    __shared__ int s_wave[kTileSortThreads / kWave];
+    __shared__ int s_nz;
     const int tile = blockIdx.x;
     const int b = tile_off[tile], e = tile_off[tile + 1];
     const int t = threadIdx.x;
@@ -286,47 +295,54 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
         d[0] = (k0 | k1) ? sort_f64_unkey(~k0) : (double)INFINITY;
         d[1] = (k0 | k1) ? sort_f64_unkey(k1) : -(double)INFINITY;
     }
-    if (t < 256) s_cnt[t] = 0;
+    const bool fine = T > 0 && T * 256 <= kTileKeysMax;  // (bin, pixel) key
+    const int nkey = T > 0 ? (fine ? T * 256 : T) : 256;
+    for (int k = t; k < nkey; k += kTileSortThreads) s_cnt[k] = 0;
+    if (t == 0) s_nz = 0;
     __syncthreads();
     auto sub_key = [&](uint32_t pk) -> int {
-        return T > 0 ? (int)(pk >> 24) : (int)((((pk & 0xFFFu) & 15u) << 4) | (((pk >> 12) & 0xFFFu) & 15u));
+        const int pix = (int)((((pk & 0xFFFu) & 15u) << 4) | (((pk >> 12) & 0xFFFu) & 15u));
+        return T > 0 ? (fine ? (int)(pk >> 24) * 256 + pix : (int)(pk >> 24)) : pix;
     };
     for (int i = b + t; i < e; i += kTileSortThreads) atomicAdd(&s_cnt[sub_key(in.evp[i].x)], 1);
     __syncthreads();
-    // exclusive scan of the 256 counters (threads 0..255): inclusive over each wave, then the wave totals
-    int c = 0, excl = 0;
+    // exclusive scan of the nkey counters in place: thread t owns `per` consecutive counters
+    const int per = (nkey + kTileSortThreads - 1) / kTileSortThreads;
+    const int k0 = t * per, k1 = min(k0 + per, nkey);
+    int sum = 0, nz = 0;
+    for (int k = k0; k < k1; ++k) {
+        sum += s_cnt[k];
+        nz += s_cnt[k] != 0;
+    }
     const int lane = t & (kWave - 1), wave = t / kWave;
-    if (t < 256) {
-        c = s_cnt[t];
-        int incl = c;
+    int incl = sum;
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const int v = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += v;
-        }
-        if (lane == kWave - 1) s_wave[wave] = incl;
-        excl = incl - c;
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += v;
+    }
+    if (lane == kWave - 1) s_wave[wave] = incl;
+    if (T == 0 && active) {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) nz += __shfl_xor(nz, o, kWave);
+        if (lane == 0 && nz) atomicAdd(&s_nz, nz);
     }
     __syncthreads();
-    if (t < 256) {
-        for (int w = 0; w < wave; ++w) excl += s_wave[w];
-        s_cur[t] = excl;
-        if (T > 0) {
-            if (t < T) group_start[tile * T + t] = b + excl;
-        } else if (t == 0) {
-            group_start[tile] = b;
-        }
-        if (tile == ntiles - 1 && t == 0) group_start[T > 0 ? ntiles * T : ntiles] = e;
-        if (T == 0 && active) {
-            int nz = c != 0;
-#pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) nz += __shfl_xor(nz, o, kWave);
-            if (lane == 0) s_wave2[wave] = nz;
-        }
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    for (int k = k0; k < k1; ++k) {
+        const int c = s_cnt[k];
+        s_cnt[k] = run;  // first position of key k, relative to the tile
+        if (T > 0 && (fine ? (k & 255) == 0 : true)) group_start[tile * T + (fine ? k >> 8 : k)] = b + run;
+        run += c;
+    }
+    if (t == 0) {
+        if (T == 0) group_start[tile] = b;
+        if (tile == ntiles - 1) group_start[T > 0 ? ntiles * T : ntiles] = e;
     }
     __syncthreads();
     // one plain store per tile: thousands of atomics on one counter serialise (12 ns each: 170 us for 3600 tiles)
-    if (T == 0 && active && t == 0) active[tile] = s_wave2[0] + s_wave2[1] + s_wave2[2] + s_wave2[3];
+    if (T == 0 && active && t == 0) active[tile] = s_nz;
     // two events per thread and round: the loads of a round are independent of its LDS atomics
     for (int i0 = b + 2 * t; i0 < e; i0 += 2 * kTileSortThreads) {
         const bool two = i0 + 1 < e;
@@ -341,7 +357,7 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
             }
         }
         const double ta = in.tau64[i0], tb = two ? in.tau64[i0 + 1] : 0.0;
-        const int pa = b + atomicAdd(&s_cur[sub_key(ea.x)], 1);
+        const int pa = b + atomicAdd(&s_cnt[sub_key(ea.x)], 1);
         out.evp[pa] = ea;
         if (frac) {
             out.rx[pa] = rxa;
@@ -349,7 +365,7 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
         }
         out.tau64[pa] = ta;
         if (two) {
-            const int pb = b + atomicAdd(&s_cur[sub_key(eb.x)], 1);
+            const int pb = b + atomicAdd(&s_cnt[sub_key(eb.x)], 1);
             out.evp[pb] = eb;
             if (frac) {
                 out.rx[pb] = rxb;
