@@ -14,6 +14,7 @@ from event_based_optical_flow_amd.solver.scipy_autograd import TorchWrapper, min
 from oracle import oracle as orc  # noqa: E402
 
 TOL = 1e-4
+HVP_TOL = 1e-4  # exact Hessian-vector products against the reference's vhp: measured 2e-7 ... 6e-6 (VERDICT r1 asked for the gate to follow)
 YAML_HYBRID = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01}
 
 
@@ -147,8 +148,8 @@ def test_native_plan_hvp_against_reference_vhp(golden, tag, scale):
     ref = np.asarray(gh[k + "__vhp"], dtype=np.float64).reshape(-1)
     for _ in range(5):  # eager calls, capture, replay
         hv = obj.hvp_numpy(x, v)
-        assert rel_max(hv, ref) <= 1e-3, rel_max(hv, ref)
-    assert rel_max(obj.hvp_numpy(x, 3.0 * v), 3.0 * ref) <= 1e-3  # linear in v (the tangent is normalised inside)
+        assert rel_max(hv, ref) <= HVP_TOL, rel_max(hv, ref)
+    assert rel_max(obj.hvp_numpy(x, 3.0 * v), 3.0 * ref) <= HVP_TOL  # linear in v (the tangent is normalised inside)
 
 
 @pytest.mark.parametrize("graphs", [False, True])
@@ -272,7 +273,7 @@ HVP_CASES += [("voxel", "dense-flow-voxel", "voxel", "image_variance", 1)]
 @pytest.mark.parametrize("mname,model,mkey,cost,sigma", HVP_CASES)
 def test_exact_hvp_against_reference_vhp(golden, mname, model, mkey, cost, sigma):
     """cmax_objective_hvp vs torch.autograd.functional.vhp run on the reference (hvp_cases.npz).
-    Tolerance 1e-3 of the largest entry: fp32 events, fixed-point tangent votes."""
+    Tolerance 1e-4 of the largest entry (fp32 events, fixed-point tangent votes; measured 2e-7 ... 6e-6)."""
     g, o = golden("hvp_cases"), golden("objective")
     size = tuple(int(v) for v in o["image_size"])
     tb = o[mkey].shape[0] if model == "dense-flow-voxel" else 0
@@ -282,7 +283,8 @@ def test_exact_hvp_against_reference_vhp(golden, mname, model, mkey, cost, sigma
     m = torch.tensor(o[mkey], dtype=torch.float64, device="cuda")
     v = torch.tensor(g[tag + "__v"], dtype=torch.float64, device="cuda")
     hv = obj.hvp(m, v).cpu().numpy()
-    assert rel_max(hv, g[tag + "__vhp"]) <= 1e-3, (np.abs(hv - g[tag + "__vhp"]).max(), np.abs(g[tag + "__vhp"]).max())
+    print(f"[hvp] {tag}: rel err {rel_max(hv, g[tag + '__vhp']):.2e}")
+    assert rel_max(hv, g[tag + "__vhp"]) <= HVP_TOL, (np.abs(hv - g[tag + "__vhp"]).max(), np.abs(g[tag + "__vhp"]).max())
 
 
 def test_exact_hvp_through_the_patch_interpolation(golden):
@@ -584,4 +586,4 @@ def test_hvp_inverse_weights_golden(golden, case):
     hv = obj.hvp(m.detach(), torch.tensor(g[k + "__v"], dtype=torch.float64, device="cuda")).cpu().numpy()
     e = rel_max(hv, g[k + "__vhp"])
     print(f"[hvp inv] {k} {cww}: rel err {e:.2e}")
-    assert e <= 1e-3, e
+    assert e <= HVP_TOL, e
