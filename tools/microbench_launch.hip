@@ -51,9 +51,29 @@ int main() {
         hipLaunchKernelGGL(k_touch, dim3(704), dim3(256), 0, s, idx, src, dst, n);
         hipLaunchKernelGGL(k_touch, dim3(704), dim3(512), 0, s, idx, src, dst, n);
     }, iters);
+    // the same triple replayed from a hipGraph (one graph launch per evaluation; 1 and 8 evaluations per graph)
+    double g1 = 0, g8 = 0;
+    for (int reps : {1, 8}) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+        for (int r = 0; r < reps; ++r) {
+            hipLaunchKernelGGL(k_touch, dim3(704), dim3(256), 0, s, idx, src, dst, n);
+            hipLaunchKernelGGL(k_touch, dim3(704), dim3(512), 0, s, idx, src, dst, n);
+            hipLaunchKernelGGL(k_touch, dim3(1), dim3(256), 0, s, idx, src, dst, n);
+        }
+        hipStreamEndCapture(s, &g);
+        hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        const double t = time_us([&] { hipGraphLaunch(ge, s); }, iters / reps) / reps;
+        (reps == 1 ? g1 : g8) = t;
+        hipGraphExecDestroy(ge);
+        hipGraphDestroy(g);
+    }
     printf("one empty launch 704x256, back to back                         %6.2f us per launch\n", e1);
     printf("three dependent EMPTY launches (704x256, 704x512, 1x256)       %6.2f us per triple\n", e3);
     printf("three dependent launches, two dependent memory trips each      %6.2f us per triple\n", t3);
     printf("two dependent launches (704x256, 704x512), same kernels        %6.2f us per pair\n", t2);
+    printf("the triple with memory trips replayed from a hipGraph (1 per graph)  %6.2f us per triple\n", g1);
+    printf("the triple with memory trips replayed from a hipGraph (8 per graph)  %6.2f us per triple\n", g8);
     return 0;
 }
