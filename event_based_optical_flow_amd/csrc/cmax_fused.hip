@@ -14,7 +14,8 @@
 //                   atomicAdd per touched window pixel; publishes its windows for K3
 //   K2  image kernels: k_stats (fp64 sums of the contrast function into `nsub` sub-accumulators per
 //                   image: same-address fp64 atomics serialise at ~12 ns), or fused with what follows --
-//                   k_blur_stats_var + k_gimage_blur_adj_var (variance with blur),
+//                   k_blur_stats_adj_var (variance with blur and a gradient: ONE kernel, the mean comes from K1's vote sums;
+//                   value-only / multi-GPU: k_blur_stats_var + k_gimage_blur_adj_var),
 //                   k_stats_gimage_gm / k_blur_stats_gimage_gm (gradient magnitude: statistics + the
 //                   unscaled G = dL/dIWE, blurs included).  They also clear the OTHER vote buffer for
 //                   the next evaluation (double buffering: no memset in the steady state) and the
@@ -47,6 +48,7 @@
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
 //   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
+//   CMAX_NO_FUSED_BLURVAR=1  blurred variance: k_blur_stats_var + k_gimage_blur_adj_var instead of k_blur_stats_adj_var
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
 //   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
 //   CMAX_PLAN_GRAPHS=1   replay the patch plan from captured hipGraphs (cmax_solver.hip)
@@ -91,6 +93,10 @@ struct RefArgs {
     float *zero[4];   // K3, deferred statistics: vote image of the NEXT evaluation to clear (or null)
     int k0;           // index of the first reference time of this launch (statistics slot, partial-sum offset)
     int4 *win;        // [n_ref][nseg] LDS windows: written by K1, read by K3 of the same evaluation (or null)
+    // K1, blurred variance with a gradient: sum_p I[p] B[p] (B = blur^T 1_Omega = b(r) b(c)) = the sum of the blurred image over
+    // Omega, accumulated while the votes are flushed -- the image kernel then knows the mean before it has blurred anything
+    double *musum[4];        // kMuLines accumulators (one 128-byte line each) per reference time, or null
+    float band_b0, band_b1;  // b(0) = b(n - 1) and b(1) = b(n - 2) of border_weight (b = 1 elsewhere)
     // deterministic mode (cmax_set_deterministic): order-free integer accumulation
     long long *img64[4];       // K1: 2^-20 fixed-point vote image, 64-bit integer atomics instead of fp32 ones (or null)
     const unsigned *imax;      // K3: bits of max |image k| per statistics slot (the bound the fixed-point scale is derived from)
@@ -155,6 +161,9 @@ struct cmax_handle_s {
     int cur_buf = 0;
     unsigned zero_mask[2] = {0u, 0u};
     double *d_gpart = nullptr;  // [4 reference times][nseg][2 (or 6: deferred statistics)] per-segment 2-DoF partials
+    double *d_musum = nullptr;  // [2 buffers][4 reference times][kMuStride] K1's sums for the blurred variance (RefArgs::musum)
+    int mu_buf = 0;             // buffer the next evaluation adds into (the other one is being cleared / is clear)
+    bool mu_valid = false;      // the K1 launch of the current cmax_objective call filled d_musum[mu_buf]
     // orig-IWE cache key
     bool orig_valid = false;
     double orig_sigma = -1;
@@ -877,6 +886,104 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
     if (threadIdx.x == 0) atomic_add(&stat_slot[kSubStride * (blockIdx.x % nsub)], v[0]);
 }
 
+// Blurred variance cost with a gradient, whole image side of one reference time in ONE kernel (k_blur_stats_var +
+// k_gimage_blur_adj_var are two dependent launches of ~4.7 + 5.0 us on a 260 x 346 image):
+//   G = c blur3^T [ (Ib - mu) 1_Omega ],  c = coef 2 / (n - 1)
+// needs the mean of the blurred image before the transpose can start.  The blur is linear: sum_Omega Ib = sum_p I[p] B[p] with
+// B = blur3^T 1_Omega = b(r) b(c), b = 1 except within two pixels of the border (border_weight) -- a sum over the VOTES: the number
+// of events, plus what K1's workgroups along the border add up (RefArgs::musum).  The mean only matters where B or the mask
+// 1_Omega vary (everywhere else the gather's differences cancel it), so the 2^-20 rounding of the fixed-point weights inside
+// "four weights add up to 1" is immaterial.  So this kernel reads mu, blurs, sums (for the loss) and writes
+// G' = 2 / (n - 1) blur3^T [ (Ib - mu) 1_Omega ]; K3 (kFoldScale) multiplies by coef once the statistics are complete.
+// One 8 x 32 output tile per workgroup, halo 2 -> 1 -> 0 in LDS; arithmetic of the blur as in k_blur3.
+constexpr int kMuLines = 32;                       // accumulators of K1's sum (same-line atomics serialise: one line each)
+constexpr int kMuStride = kMuLines * kSubStride;   // doubles per reference time
+__global__ void __launch_bounds__(256)
+k_blur_stats_adj_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
+                     float4 *__restrict__ zero_extra, int64_t n_extra4, const double *__restrict__ musum, double *__restrict__ musum_next,
+                     int64_t n_events) {
+    constexpr int TH = 8, TW = 32;
+    __shared__ float s_mu;
+    if (threadIdx.x < kWave) {  // issued first: the latency hides behind the tile loads
+        double m = threadIdx.x < kMuLines ? musum[blockIdx.y * kMuStride + threadIdx.x * kSubStride] : 0.0;
+        m = wave_sum_lane63(m);
+        if (threadIdx.x == kWave - 1) s_mu = (float)(((double)n_events + m) / region_pixels(H, W, omit));
+        // the accumulators of the NEXT evaluation (the other buffer: nobody reads or adds to it during this one), written through
+        if (blockIdx.x == 0 && threadIdx.x < kMuLines)
+            __hip_atomic_store(&musum_next[blockIdx.y * kMuStride + threadIdx.x * kSubStride], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float *__restrict__ img = ia.in[blockIdx.y];
+    float *__restrict__ blurred = ia.blurred[blockIdx.y];
+    float *__restrict__ zero_img = ia.zero[blockIdx.y];
+    float *__restrict__ G = ia.G[blockIdx.y];
+    double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
+    if (blockIdx.y > 0) n_extra4 = 0;  // the flow-gradient buffer is cleared once
+    __shared__ double smem[2 * 4];
+    __shared__ float t_i[TH + 4][TW + 4 + 1];  // raw image, halo 2 (only in-image cells are read)
+    __shared__ float t_b[TH + 2][TW + 2 + 1];  // blurred image, halo 1
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
+    const int tiles_w = (W + TW - 1) / TW;
+    const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
+    const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
+    const int i0 = omit ? 1 : 0;
+    auto in_img = [&](int r, int c) { return (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W; };
+    for (int q = threadIdx.x; q < (TH + 4) * (TW + 4); q += 256) {
+        const int a = q / (TW + 4), b = q - a * (TW + 4), r = R0 - 2 + a, c = C0 - 2 + b;
+        t_i[a][b] = in_img(r, c) ? img[(int64_t)r * W + c] : 0.f;
+    }
+    __syncthreads();
+    zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
+    zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
+    for (int q = threadIdx.x; q < (TH + 2) * (TW + 2); q += 256) {
+        const int a = q / (TW + 2), b = q - a * (TW + 2), r = R0 - 1 + a, c = C0 - 1 + b;
+        float v = 0.f;
+        if (in_img(r, c)) {  // reflect-101 neighbours are at most one pixel away: inside the halo-2 tile
+            const int rm = refl101(r - 1, H) - (R0 - 2), rr = r - (R0 - 2), rp = refl101(r + 1, H) - (R0 - 2);
+            const int cm = refl101(c - 1, W) - (C0 - 2), cc = c - (C0 - 2), cp = refl101(c + 1, W) - (C0 - 2);
+            auto row = [&](int y) { return k1 * t_i[y][cm] + k0 * t_i[y][cc] + k1 * t_i[y][cp]; };
+            v = k1 * row(rm) + k0 * row(rr) + k1 * row(rp);
+        }
+        t_b[a][b] = v;
+    }
+    __syncthreads();
+    const float gscale = (float)(2.0 / (region_pixels(H, W, omit) - 1.0));
+    const int la = threadIdx.x / TW, lb = threadIdx.x - la * TW;
+    const int i = R0 + la, j = C0 + lb;
+    double v[2] = {0.0, 0.0};
+    if (i < H && j < W) {
+        const int64_t p = (int64_t)i * W + j;
+        const float b = t_b[la + 1][lb + 1];
+        blurred[p] = b;
+        const float mu = s_mu;  // (published by the barriers above)
+        auto d = [&](int r, int c) -> float {  // (Ib - mu) 1_Omega
+            const bool in = (r >= i0) && (r < H - i0) && (c >= i0) && (c < W - i0);
+            return in ? t_b[r - (R0 - 1)][c - (C0 - 1)] - mu : 0.f;
+        };
+        G[p] = gscale * blur_adj_1d<float>(i, H, k0, k1, [&](int r) { return blur_adj_1d<float>(j, W, k0, k1, [&](int c) { return d(r, c); }); });
+        if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) {
+            v[0] = (double)b;
+            v[1] = (double)b * (double)b;
+        }
+    }
+    block_sum<2>(v, smem);
+    if (threadIdx.x == 0) {
+        double *a = stat_slot + kSubStride * (blockIdx.x % nsub);
+        atomic_add(&a[0], v[0]);
+        atomic_add(&a[1], v[1]);
+    }
+}
+
+// b(p) of B = blur3^T 1_Omega along one axis of length n >= 4 (Omega = [i0, n - i0)): b(0) = b(n - 1), b(1) = b(n - 2), 1 elsewhere
+static float border_weight(int p, int n, int i0, float k0, float k1) {
+    auto one = [&](int r) { return (r >= i0 && r < n - i0) ? 1.f : 0.f; };
+    float s = k0 * one(p);
+    if (p - 1 >= 0) s += k1 * one(p - 1);
+    if (p + 1 < n) s += k1 * one(p + 1);
+    if (p == 1) s += k1 * one(0);      // the reflected taps of blur_adj_1d
+    if (p == n - 2) s += k1 * one(n - 1);
+    return s;
+}
+
 // 2-DoF, plain variance, tangent images (k_vote_tan2): everything the loss and the gradient need, in image space.
 //   With m = 1_Omega (zero outside the image) and G = c (I - mu) m:
 //     dL/dtheta0 = sum_q E0[q] (G~[q + (1,0)] - G~[q]) = c (S1x - mu S2x),
@@ -1309,11 +1416,14 @@ template <int MODEL>
 static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, hipStream_t s) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     ProfScope prof(h, kProfVote, s);
-#define CMAX_LAUNCH_VOTE(NS, FRAC) \
-    hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra)
+#define CMAX_LAUNCH_VOTE(NS, FRAC)                                                                                           \
+    do {                                                                                                                    \
+        if (ra.musum[0]) hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC, true>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra); \
+        else hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);     \
+    } while (0)
     static const int force = forced_ns("CMAX_VOTE_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (force ? force == 512 : wide_groups(h)) {
+        if (force ? force == 512 : h->nseg > 512) {  // as for K3: cfg2 (704 half-tile segments) K1 6.35 -> 5.97 us, evaluation 18.06 -> 17.38
             if (h->has_frac) CMAX_LAUNCH_VOTE(t512, true);
             else CMAX_LAUNCH_VOTE(t512, false);
         } else {
@@ -1431,8 +1541,10 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
 
 // raw votes of n_ref reference times (one launch) into imgs[k] (cleared here unless bit k of zero_mask says it is
 // zero already); stat_slot0 >= 0: the statistics accumulators of slots stat_slot0 + k are reset by the launch
+// mu_taps: non-null = also accumulate sum_p I[p] B[p] for the blurred variance (taps k0, k1 of the blur, omit_boundary in [2])
 static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, int n_ref, const int *ref_mode, const double *ref_frac,
-                       int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s, bool publish_windows = false) {
+                       int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s, bool publish_windows = false,
+                       const float *mu_taps = nullptr) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     RefArgs ra = {};
     ra.k0 = 0;
@@ -1456,6 +1568,12 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
         ra.d[k] = ref_fraction(ref_mode[k], ref_frac[k]);
         ra.img[k] = imgs[k];
         ra.stat[k] = stat_zero;
+        if (mu_taps && !det && h->n > 0) ra.musum[k] = h->d_musum + ((int64_t)h->mu_buf * 4 + k) * kMuStride;
+    }
+    if (mu_taps) h->mu_valid = ra.musum[0] != nullptr;
+    if (ra.musum[0]) {
+        ra.band_b0 = border_weight(0, h->Hp, (int)mu_taps[2], mu_taps[0], mu_taps[1]);
+        ra.band_b1 = border_weight(1, h->Hp, (int)mu_taps[2], mu_taps[0], mu_taps[1]);
     }
     if (h->n == 0) return 0;
     const EvView ev = ev_view(h);
@@ -1815,6 +1933,11 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     if (!rc) rc = dev_alloc(h, &h->cursor, h->nkeys);
     if (!rc) rc = dev_alloc(h, &h->scan_tmp, div_up(h->nkeys, kScanChunk) + 1);
     if (!rc) rc = dev_alloc(h, &h->d_flags, 4);
+    if (!rc) rc = dev_alloc(h, &h->d_musum, 2 * 4 * kMuStride);
+    if (!rc && hipMemset(h->d_musum, 0, 2 * 4 * kMuStride * sizeof(double)) != hipSuccess) {
+        set_error("cmax_create: clearing the accumulators failed");
+        rc = CMAX_ENOMEM;
+    }
     if (!rc) rc = dev_alloc(h, &h->d_tile_start, h->ntr * h->ntc * 256 + 1);  // up to 255 time bins per tile
     if (rc) {
         cmax_destroy(h);
@@ -1841,6 +1964,7 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->Gt);
     dev_free(&h->d_tmm);
     dev_free(&h->d_stat);
+    dev_free(&h->d_musum);
     dev_free(&h->hvp_img);
     dev_free(&h->d_stat_tan);
     dev_free(&h->search_range);
@@ -1983,12 +2107,21 @@ static bool orig_cache_hit(const cmax_handle_s *h, const cmax_objective_t *d) {
 // votes of every reference time (+ the un-warped image when needed) into images[0 .. n_images);
 // zero_mask bit k: images[k] is already zero (the handle's double-buffered images)
 static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
-                          int *n_images_out, hipStream_t s) {
+                          int *n_images_out, hipStream_t s, bool want_mu = false) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
+    h->mu_valid = false;
     {
         float *imgs[4];
         for (int k = 0; k < d->n_ref; ++k) imgs[k] = images + k * npix;
-        int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s, true);
+        float mu_taps[3] = {0.f, 0.f, d->omit_boundary ? 1.f : 0.f};
+        if (want_mu) {
+            double k0 = 0, k1 = 0;
+            blur_taps(d->sigma, k0, k1);
+            mu_taps[0] = (float)k0;
+            mu_taps[1] = (float)k1;
+        }
+        int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s, true,
+                             want_mu ? mu_taps : nullptr);
         if (rc) return rc;
     }
     int n_images = d->n_ref;
@@ -2055,6 +2188,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // gradient magnitude with a gradient: K2 and K2b (and the blurs) are one kernel: statistics + G image without its chain factor
     const bool fused_gm = !det && grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
     const bool blur_var = !det && d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
+    // ... with a gradient: + the un-centred, unscaled A' = 2 / (n - 1) blur^T [Ib 1_Omega] (k_blur_stats_adj_var); K3 applies the
+    // chain factor (kFoldScale) and, along the image border, the mean
+    const bool fused_bv = blur_var && grad && h->n > 0 && reuse_windows && h->mu_valid;  // (decided by objective_eval: blurvar_from_votes)
     // owned groups: K3 stores every element of the flow gradient itself (one writer per pixel) -- nothing to clear.
     // Needs the group-aligned work list, ONE reference time (several would add into the same pixels) and the sort
     // order that matches the model (dense: tiles; voxel: (tile, bin) of the same T).
@@ -2078,7 +2214,16 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
 
     // ---- contrast statistics
-    if (blur_var) {
+    if (fused_bv) {
+        ProfScope prof(h, kProfStats, s);
+        for (int rep = 0; rep < h->prof_repeat; ++rep)
+            hipLaunchKernelGGL(k_blur_stats_adj_var, gm_grid, dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary, op.nsub,
+                               h->d_stat, clear4, nclear4, h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride,
+                               h->d_musum + (int64_t)(h->mu_buf ^ 1) * 4 * kMuStride, h->n);
+        CMAX_CHECK_LAUNCH();
+        h->mu_buf ^= 1;  // the next evaluation adds into the buffer this launch cleared
+        h->mu_valid = false;
+    } else if (blur_var) {
         ProfScope prof(h, kProfStats, s);
         for (int rep = 0; rep < h->prof_repeat; ++rep)
             hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h), d->n_ref), dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary,
@@ -2106,7 +2251,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
 
     // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
     if (!two_dof && !grad_cleared_by_stats && !owned && !det) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
-    const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : (fused_gm ? kFoldScale : kFoldNone));
+    const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : ((fused_gm || fused_bv) ? kFoldScale : kFoldNone));
     if (det) {
         // bound of the per-event terms: max |image the contrast is evaluated on| per reference time (integer max: order-free)
         CMAX_CHECK_HIP(hipMemsetAsync(h->d_imax, 0, kStatSlots * sizeof(unsigned), s));
@@ -2141,7 +2286,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             CMAX_CHECK_HIP(hipMemsetAsync(h->g64, 0, (size_t)gcount * sizeof(long long), s));
         }
     }
-    if (blur_var) {
+    if (fused_bv) {
+        // dL/dIWE was written (without mean and chain factor) by the statistics kernel
+    } else if (blur_var) {
         ImgArgs ib = ia;
         for (int k = 0; k < d->n_ref; ++k) ib.in[k] = h->iweb[k];
         ProfScope prof(h, kProfGimage, s);
@@ -2299,7 +2446,12 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     float *cur = h->imgs + (int64_t)h->cur_buf * 5 * npix;
     float *nxt = h->imgs + (int64_t)(h->cur_buf ^ 1) * 5 * npix;
     int n_images = 0;
-    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s);
+    // blurred variance with a gradient on one GPU: K1 also sums the votes against blur^T 1_Omega, so that ONE image kernel can
+    // blur, sum and write dL/dIWE (k_blur_stats_adj_var).  Across GPUs the sum would need its own exchange: two image kernels.
+    static const bool no_fused_bv = getenv("CMAX_NO_FUSED_BLURVAR") != nullptr;  // tuning: k_blur_stats_var + k_gimage_blur_adj_var
+    const bool blurvar_from_votes = !dist && grad && !h->deterministic && h->n > 0 && d->cost == CMAX_COST_VARIANCE && d->sigma > 0 &&
+                                    h->Hp >= 4 && h->Wp >= 4 && !no_fused_bv;
+    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes);
     if (rc) return rc;
     const unsigned used = (1u << n_images) - 1u;
     h->zero_mask[h->cur_buf] &= ~used;  // now holds votes
