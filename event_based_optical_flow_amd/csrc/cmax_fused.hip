@@ -48,6 +48,7 @@
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
 //   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
+//   CMAX_NO_STATS_INSIDE=1   plain variance on owned groups: k_stats as a launch of its own instead of inside K3's
 //   CMAX_NO_FUSED_BLURVAR=1  blurred variance: k_blur_stats_var + k_gimage_blur_adj_var instead of k_blur_stats_adj_var
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
 //   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
@@ -96,6 +97,10 @@ struct RefArgs {
     // K1, blurred variance with a gradient: sum_p I[p] B[p] (B = blur^T 1_Omega = b(r) b(c)) = the sum of the blurred image over
     // Omega, accumulated while the votes are flushed -- the image kernel then knows the mean before it has blurred anything
     double *musum[4];        // kMuLines accumulators (one 128-byte line each) per reference time, or null
+    // K3, kFoldStatsInside: musum[k] is READ (the mean), and
+    int stat_blocks;         // leading workgroups of the grid that run the statistics (a multiple of 8: the XCD map of the others holds)
+    int *ticket;             // their arrival counters (kTicketLines lines, zero between launches): the last one writes the loss
+    double *musum_next;      // the other buffer of the vote sums: cleared for the next evaluation
     float band_b0, band_b1;  // b(0) = b(n - 1) and b(1) = b(n - 2) of border_weight (b = 1 elsewhere)
     // deterministic mode (cmax_set_deterministic): order-free integer accumulation
     long long *img64[4];       // K1: 2^-20 fixed-point vote image, 64-bit integer atomics instead of fp32 ones (or null)
@@ -161,6 +166,7 @@ struct cmax_handle_s {
     int cur_buf = 0;
     unsigned zero_mask[2] = {0u, 0u};
     double *d_gpart = nullptr;  // [4 reference times][nseg][2 (or 6: deferred statistics)] per-segment 2-DoF partials
+    int *d_ticket = nullptr;    // arrival counters of the statistics workgroups inside K3 (kFoldStatsInside): zero between launches
     double *d_musum = nullptr;  // [2 buffers][4 reference times][kMuStride] K1's sums for the blurred variance (RefArgs::musum)
     int mu_buf = 0;             // buffer the next evaluation adds into (the other one is being cleared / is clear)
     bool mu_valid = false;      // the K1 launch of the current cmax_objective call filled d_musum[mu_buf]
@@ -428,12 +434,12 @@ __device__ __forceinline__ float time_scale(const WarpParams &wp) {
 // Workgroup -> segment, XCD-aware: the dispatcher places block b on XCD b % 8, so giving XCD x the
 // contiguous range [x * per, (x+1) * per) keeps neighbouring tiles (shared halo rows of the IWE / G
 // windows, neighbouring flow pixels) in one XCD's L2.  Placement only affects speed.
-__device__ __forceinline__ int segment_of_block(int nseg) {
+__device__ __forceinline__ int segment_of_block(int nseg, unsigned bx = blockIdx.x) {
 #ifdef CMAX_NO_XCD_MAP
-    return (int)blockIdx.x;
+    return (int)bx;
 #else
     const int per = (nseg + 7) >> 3;
-    return (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    return (int)(bx & 7u) * per + (int)(bx >> 3);
 #endif
 }
 
@@ -446,6 +452,10 @@ struct Window {
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
 constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3;  // kFoldScale: G image stored without its chain factor
+// kFoldStatsInside: kFoldStats for a plain (not normalised) variance whose K2 runs INSIDE the K3 launch -- the first
+// RefArgs::stat_blocks workgroups of the grid are k_stats (they also write the loss), the others gather; nothing in the
+// gradient waits for the statistics: the chain factor is a constant and the mean comes from K1's vote sums (RefArgs::musum)
+constexpr int kFoldStatsInside = 4;
 constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2, kGradDet = 3;  // k_grad's VARIANT (see cmax_event_kernels.inc)
 constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
@@ -627,6 +637,40 @@ __device__ __forceinline__ double chain_coef(const ObjParams &op, const double *
         coef = op.mult[k] * (op.minimize ? -v_orig / (v * v) : 1.0 / v_orig);
     }
     return op.negate ? -coef : coef;
+}
+
+// Arrival ticket of a group of workgroups inside one launch: called by ONE thread of workgroup `wg` of `total` after its
+// device-scope atomics; true for exactly one caller, the last to arrive, and every other workgroup's atomics have been
+// performed by then (the caller waits for its own acknowledgements first).  The counters are left at zero.  Same-line atomics
+// serialise, hence kTicketSubs lines + one.  Four dependent fabric round trips (~5 us, profiles/r02_ablation.txt): only for work
+// that is NOT at the end of its kernel.
+constexpr int kTicketSubs = 16, kTicketLines = kTicketSubs + 1, kTicketLineInts = 32;
+__device__ __forceinline__ bool arrive_last(int *ticket, int wg, int total) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nsub = total < kTicketSubs ? total : kTicketSubs;
+    const int sub = wg % kTicketSubs, per = (total - sub + kTicketSubs - 1) / kTicketSubs;
+    int *line = ticket + sub * kTicketLineInts;
+    if (__hip_atomic_fetch_add(line, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != per - 1) return false;
+    __hip_atomic_store(line, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else arrives on this line any more
+    int *master = ticket + kTicketSubs * kTicketLineInts;
+    if (__hip_atomic_fetch_add(master, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nsub - 1) return false;
+    __hip_atomic_store(master, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// loss of a plain variance objective with ONE reference time from accumulators that other workgroups of the same launch
+// filled with device-scope atomics: device-scope loads (a plain load may be served from this XCD's L2)
+__device__ __forceinline__ void write_result_variance_agent(const ObjParams &op, const double *stat, double *__restrict__ result) {
+    double acc[2] = {0.0, 0.0};
+    for (int u = 0; u < op.nsub; ++u) {
+        acc[0] += __hip_atomic_load(&stat[kSubStride * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc[1] += __hip_atomic_load(&stat[kSubStride * u + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double v = contrast_value(CMAX_COST_VARIANCE, acc, region_pixels(op.H, op.W, op.omit), nullptr);
+    const double loss = op.mult[0] * (op.minimize ? -v : v);
+    result[0] = op.negate ? -loss : loss;
+    result[1] = v;
+    result[5] = 0.0;
 }
 
 // loss and per-reference-time contrasts -> result[0..5]
@@ -1434,10 +1478,17 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 #undef CMAX_LAUNCH_VOTE
 }
 
+// workgroup size launch_grad picks (tuning knob CMAX_GRAD_NS aside)
+static int grad_threads(const cmax_handle_s *h, int model) {
+    static const int force = forced_ns("CMAX_GRAD_NS");
+    if (force ? (force == 1024 && model == CMAX_MODEL_VOXEL) : (model == CMAX_MODEL_VOXEL && wide_groups(h))) return 1024;
+    return (force ? force >= 512 : h->nseg > 512) ? 512 : 256;
+}
+
 template <int MODEL>
 static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, int fold,
                         const ObjParams &op, double *gpart, float *gflow, double *result, bool owned, hipStream_t s) {
-    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
+    const dim3 grid(8 * ((h->nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref);
     ProfScope prof(h, kProfGrad, s);
     if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
 #define CMAX_LAUNCH_DET(FRAC, FOLD) \
@@ -1481,6 +1532,8 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 #define CMAX_LAUNCH_GRAD_FR(NS, FRAC)                                                        \
     if (fold == kFoldDeferred) {                                                             \
         if constexpr (MODEL == CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); } \
+    } else if (fold == kFoldStatsInside) {                                                   \
+        if constexpr (MODEL != CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); } \
     } else if (fold == kFoldStats) {                                                         \
         CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);                                              \
     } else if (fold == kFoldScale) {                                                         \
@@ -1934,6 +1987,11 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     if (!rc) rc = dev_alloc(h, &h->scan_tmp, div_up(h->nkeys, kScanChunk) + 1);
     if (!rc) rc = dev_alloc(h, &h->d_flags, 4);
     if (!rc) rc = dev_alloc(h, &h->d_musum, 2 * 4 * kMuStride);
+    if (!rc) rc = dev_alloc(h, &h->d_ticket, kTicketLines * kTicketLineInts);
+    if (!rc && hipMemset(h->d_ticket, 0, kTicketLines * kTicketLineInts * sizeof(int)) != hipSuccess) {
+        set_error("cmax_create: clearing the arrival counters failed");
+        rc = CMAX_ENOMEM;
+    }
     if (!rc && hipMemset(h->d_musum, 0, 2 * 4 * kMuStride * sizeof(double)) != hipSuccess) {
         set_error("cmax_create: clearing the accumulators failed");
         rc = CMAX_ENOMEM;
@@ -1965,6 +2023,7 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->d_tmm);
     dev_free(&h->d_stat);
     dev_free(&h->d_musum);
+    dev_free(&h->d_ticket);
     dev_free(&h->hvp_img);
     dev_free(&h->d_stat_tan);
     dev_free(&h->search_range);
@@ -2104,6 +2163,14 @@ static bool orig_cache_hit(const cmax_handle_s *h, const cmax_objective_t *d) {
     return h->orig_valid && h->orig_sigma == d->sigma && h->orig_cost == d->cost && h->orig_omit == d->omit_boundary;
 }
 
+// K3 stores every element of the flow gradient itself (one writer per pixel): needs the group-aligned work list, ONE reference
+// time (several would add into the same pixels) and the sort order that matches the model (dense: tiles; voxel: (tile, bin) of
+// the same T)
+static bool owned_groups_apply(const cmax_handle_s *h, const cmax_objective_t *d, const void *grad) {
+    return !h->deterministic && grad && h->owned && h->n > 0 && d->n_ref == 1 &&
+           ((d->model == CMAX_MODEL_DENSE && h->n_time_bin == 0) || (d->model == CMAX_MODEL_VOXEL && h->n_time_bin == d->T));
+}
+
 // votes of every reference time (+ the un-warped image when needed) into images[0 .. n_images);
 // zero_mask bit k: images[k] is already zero (the handle's double-buffered images)
 static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
@@ -2115,8 +2182,8 @@ static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const floa
         for (int k = 0; k < d->n_ref; ++k) imgs[k] = images + k * npix;
         float mu_taps[3] = {0.f, 0.f, d->omit_boundary ? 1.f : 0.f};
         if (want_mu) {
-            double k0 = 0, k1 = 0;
-            blur_taps(d->sigma, k0, k1);
+            double k0 = 1, k1 = 0;  // no blur: B = 1_Omega
+            if (d->sigma > 0) blur_taps(d->sigma, k0, k1);
             mu_taps[0] = (float)k0;
             mu_taps[1] = (float)k1;
         }
@@ -2194,8 +2261,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // owned groups: K3 stores every element of the flow gradient itself (one writer per pixel) -- nothing to clear.
     // Needs the group-aligned work list, ONE reference time (several would add into the same pixels) and the sort
     // order that matches the model (dense: tiles; voxel: (tile, bin) of the same T).
-    const bool owned = !det && grad && h->owned && h->n > 0 && d->n_ref == 1 &&
-                       ((d->model == CMAX_MODEL_DENSE && h->n_time_bin == 0) || (d->model == CMAX_MODEL_VOXEL && h->n_time_bin == d->T));
+    const bool owned = owned_groups_apply(h, d, grad);
+    // plain variance, not normalised, owned groups, K1 of this call summed its votes: the statistics run inside the K3 launch
+    const bool stats_inside = owned && fold_var && !d->normalized && reuse_windows && h->mu_valid;
     const bool grad_cleared_by_stats = grad && !two_dof && !owned && !det && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
     float4 *clear4 = grad_cleared_by_stats ? (float4 *)grad : nullptr;
     const int64_t nclear4 = grad_cleared_by_stats ? gcount / 4 : 0;
@@ -2229,7 +2297,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h), d->n_ref), dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary,
                                op.nsub, h->d_stat, clear4, nclear4);
         CMAX_CHECK_LAUNCH();
-    } else if (!(deferred || fused_gm)) {  // those get their statistics from K3 / from the fused image kernel below
+    } else if (!(deferred || fused_gm || stats_inside)) {  // those get their statistics from K3 / from the fused image kernel below
         for (int k = 0; k < d->n_ref; ++k) {
             const float *img = nullptr;
             rc = blur_image(h, d->sigma, images + k * npix, h->iweb[k], &img, s);
@@ -2251,7 +2319,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
 
     // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
     if (!two_dof && !grad_cleared_by_stats && !owned && !det) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
-    const int fold = deferred ? kFoldDeferred : (fold_var ? kFoldStats : ((fused_gm || fused_bv) ? kFoldScale : kFoldNone));
+    const int fold = deferred ? kFoldDeferred : (stats_inside ? kFoldStatsInside : (fold_var ? kFoldStats : ((fused_gm || fused_bv) ? kFoldScale : kFoldNone)));
     if (det) {
         // bound of the per-event terms: max |image the contrast is evaluated on| per reference time (integer max: order-free)
         CMAX_CHECK_HIP(hipMemsetAsync(h->d_imax, 0, kStatSlots * sizeof(unsigned), s));
@@ -2314,10 +2382,20 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     for (int k = 0; k < d->n_ref; ++k) {
         ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
         ra.img[k] = (fold == kFoldNone || fold == kFoldScale) ? h->G + k * npix : const_cast<float *>(h->last_iwe[k]);
-        ra.zero[k] = deferred ? ia.zero[k] : nullptr;
+        ra.zero[k] = (deferred || stats_inside) ? ia.zero[k] : nullptr;
         same_vote = same_vote && h->win_d[k] == ra.d[k];
     }
     ra.win = same_vote ? h->d_win : nullptr;  // the windows K1 derived for exactly this warp
+    ra.n_events = h->n;
+    if (stats_inside) {
+        const int64_t per_block = 4 * (int64_t)grad_threads(h, d->model);  // pixels per workgroup and sweep, as in k_stats
+        ra.stat_blocks = (int)std::min<int64_t>(8 * div_up(div_up(npix, per_block), 8), 8 * (kStatBlocksMax / 8));
+        ra.ticket = h->d_ticket;
+        ra.musum[0] = h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride;
+        ra.musum_next = h->d_musum + (int64_t)(h->mu_buf ^ 1) * 4 * kMuStride;
+        h->mu_buf ^= 1;  // the next evaluation adds into the buffer this launch clears
+        h->mu_valid = false;
+    }
     if (det) {
         ra.imax = h->d_imax;
         ra.g64 = two_dof ? reinterpret_cast<long long *>(h->d_gpart) : h->g64;  // (d_gpart: [4][nseg][6] doubles, 2 used per segment)
@@ -2451,7 +2529,12 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     static const bool no_fused_bv = getenv("CMAX_NO_FUSED_BLURVAR") != nullptr;  // tuning: k_blur_stats_var + k_gimage_blur_adj_var
     const bool blurvar_from_votes = !dist && grad && !h->deterministic && h->n > 0 && d->cost == CMAX_COST_VARIANCE && d->sigma > 0 &&
                                     h->Hp >= 4 && h->Wp >= 4 && !no_fused_bv;
-    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes);
+    // plain variance (no blur, not normalised) on owned groups: nothing in the gradient needs the finished statistics once the
+    // mean comes from the votes, so K2 runs inside the K3 launch (kFoldStatsInside)
+    static const bool no_stats_inside = getenv("CMAX_NO_STATS_INSIDE") != nullptr;  // tuning: k_stats as a launch of its own
+    const bool var_from_votes = !dist && !no_stats_inside && owned_groups_apply(h, d, grad) && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) &&
+                                !d->normalized && h->Hp >= 4 && h->Wp >= 4;
+    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes || var_from_votes);
     if (rc) return rc;
     const unsigned used = (1u << n_images) - 1u;
     h->zero_mask[h->cur_buf] &= ~used;  // now holds votes

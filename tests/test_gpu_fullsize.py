@@ -130,3 +130,27 @@ def test_cfg5_two_time_slices_of_5m_against_the_oracle():
     print(f"[fullsize] cfg5 2 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e} | gated {e_gate:.2e} "
           f"({n_amb} cell-border events)")
     assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL
+
+
+@pytest.mark.parametrize("model,sigma,omit", [("dense-flow", 0, True), ("dense-flow", 0, False), ("dense-flow-voxel", 0, True),
+                                               ("dense-flow", 1, True), ("dense-flow", 1, False), ("dense-flow-voxel", 1, True)])
+def test_mean_from_votes_along_the_border(model, sigma, omit):
+    """The variance paths that take the image mean from K1's vote sums instead of from finished statistics (round 2:
+    k_blur_stats_adj_var for sigma > 0, the statistics inside the K3 launch for sigma = 0 on owned groups): a strong
+    flow on a small sensor, so that a large share of the votes lands in the two-pixel band along the border or leaves
+    the image -- exactly the events whose share of the mean is not simply 'one per event'."""
+    size, n, Tn = (288, 352), 700_000, 4  # 6.9 events per pixel: every 16 x 16 tile stays below one segment (owned groups)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=77)
+    f0 = E.utils.generate_smooth_flow(size, 40, seed=1077)
+    if model == "dense-flow":
+        motion, tb = f0, 0
+    else:
+        motion, tb = np.stack([f0 * (1.0 + 0.1 * k) for k in range(Tn)]), Tn
+    h = E.CMaxHandle(size).set_events(ev, time_bin=tb) if tb else E.CMaxHandle(size).set_events(ev)
+    assert h.batch_info()["owned_groups"]
+    desc = E.make_descriptor("image_variance", model, sigma=float(sigma), omit_boundary=omit, time_bin=tb)
+    ref = orc.objective(ev, motion, model, size, cost="image_variance", sigma=sigma, omit_boundary=omit)
+    bound, n_amb = ambiguity_bound(ev, motion, model, size, raw_image_grad(ref, sigma))
+    for rep in range(3):  # the vote sums are double-buffered across evaluations: every one must see clean accumulators
+        res, grad = h.evaluate(desc, motion)
+        check(f"border {model} sigma {sigma} omit {int(omit)} #{rep}", h, res, grad, ref, bound, n_amb)
