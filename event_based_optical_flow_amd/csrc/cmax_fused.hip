@@ -116,6 +116,8 @@ struct ImgArgs {
     float *blurred[4];   // blurred image to write (kernels that blur)
     float *zero[4];      // vote image of the next evaluation to clear (or null)
     float *G[4];         // dL/dIWE to write
+    float chain[4];      // fused statistics + G kernels: chain factor to fold into G (a constant of a cost that is not normalised;
+                         // 1 when it depends on the finished statistics and K3 applies it: kFoldScale)
 };
 
 }  // namespace cmax
@@ -806,7 +808,7 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
     if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     const int i0 = omit ? 1 : 0;
-    const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0);
+    const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0) * ia.chain[blockIdx.y];
     const int la = threadIdx.x / kGmTileW, lb = threadIdx.x - la * kGmTileW;  // pixel of this thread inside the tile
     const int i = r0 + 2 + la, j = c0 + 2 + lb;
     double v[2] = {0.0, 0.0};
@@ -894,7 +896,7 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
         t_gy[a][b] = ((t_b[a][b + 2] + 2.f * t_b[a + 1][b + 2] + t_b[a + 2][b + 2]) - (t_b[a][b] + 2.f * t_b[a + 1][b] + t_b[a + 2][b])) * 0.125f;
     }
     __syncthreads();
-    const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0);
+    const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0) * ia.chain[blockIdx.y];
     for (int q = threadIdx.x; q < (TH + 2) * (TW + 2); q += 256) {
         const int a = q / (TW + 2), b = q - a * (TW + 2), r = R0 - 1 + a, c = C0 - 1 + b;
         float sum = 0.f;
@@ -990,7 +992,7 @@ k_blur_stats_adj_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int
         t_b[a][b] = v;
     }
     __syncthreads();
-    const float gscale = (float)(2.0 / (region_pixels(H, W, omit) - 1.0));
+    const float gscale = (float)(2.0 / (region_pixels(H, W, omit) - 1.0)) * ia.chain[blockIdx.y];
     const int la = threadIdx.x / TW, lb = threadIdx.x - la * TW;
     const int i = R0 + la, j = C0 + lb;
     double v[2] = {0.0, 0.0};
@@ -2278,6 +2280,8 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         ia.blurred[k] = h->iweb[k];
         ia.zero[k] = zero_next ? zero_next + k * npix : nullptr;
         ia.G[k] = h->G + k * npix;
+        // not normalised: the chain factor of chain_coef is a constant -- the fused image kernels fold it into G and K3 reads a finished image
+        ia.chain[k] = op.normalized ? 1.f : (float)((op.negate ? -1.0 : 1.0) * op.mult[k] * (op.minimize ? -1.0 : 1.0));
         h->last_iwe[k] = d->sigma > 0 ? h->iweb[k] : images + k * npix;  // the image the contrast is evaluated on
     }
 
@@ -2319,7 +2323,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
 
     // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
     if (!two_dof && !grad_cleared_by_stats && !owned && !det) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
-    const int fold = deferred ? kFoldDeferred : (stats_inside ? kFoldStatsInside : (fold_var ? kFoldStats : ((fused_gm || fused_bv) ? kFoldScale : kFoldNone)));
+    const int fold = deferred ? kFoldDeferred
+                              : (stats_inside ? kFoldStatsInside
+                                              : (fold_var ? kFoldStats : (((fused_gm || fused_bv) && d->normalized) ? kFoldScale : kFoldNone)));
     if (det) {
         // bound of the per-event terms: max |image the contrast is evaluated on| per reference time (integer max: order-free)
         CMAX_CHECK_HIP(hipMemsetAsync(h->d_imax, 0, kStatSlots * sizeof(unsigned), s));
