@@ -48,6 +48,7 @@
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
 //   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
+//   CMAX_STAT_SWEEPS=n       ... and how many 4-pixel sweeps each of those workgroups makes (fewer, longer workgroups)
 //   CMAX_NO_STATS_INSIDE=1   plain variance on owned groups: k_stats as a launch of its own instead of inside K3's
 //   CMAX_NO_FUSED_BLURVAR=1  blurred variance: k_blur_stats_var + k_gimage_blur_adj_var instead of k_blur_stats_adj_var
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
@@ -2394,7 +2395,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     ra.win = same_vote ? h->d_win : nullptr;  // the windows K1 derived for exactly this warp
     ra.n_events = h->n;
     if (stats_inside) {
-        const int64_t per_block = 4 * (int64_t)grad_threads(h, d->model);  // pixels per workgroup and sweep, as in k_stats
+        // two sweeps of 4 pixels per thread (cfg5, K3 with 1 / 2 / 4 / 8 sweeps: 18.8 / 17.9 / 18.3 / 18.3 us; tuning: CMAX_STAT_SWEEPS)
+        static const int sweeps = getenv("CMAX_STAT_SWEEPS") ? std::max(1, atoi(getenv("CMAX_STAT_SWEEPS"))) : 2;
+        const int64_t per_block = 4 * (int64_t)grad_threads(h, d->model) * sweeps;
         ra.stat_blocks = (int)std::min<int64_t>(8 * div_up(div_up(npix, per_block), 8), 8 * (kStatBlocksMax / 8));
         ra.ticket = h->d_ticket;
         ra.musum[0] = h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride;
