@@ -245,14 +245,16 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
             step()
         torch.cuda.synchronize()
         prof_single = handle.read_profile()
-        handle.set_profiling(True, repeat=REPEAT)
-        for _ in range(max(psteps // 4, 10)):
-            step()
-        torch.cuda.synchronize()
-        prof = handle.read_profile()
+        chunks = []  # five short passes, median per class: one disturbed bracket must not move a 7 us figure
+        for _ in range(5):
+            handle.set_profiling(True, repeat=REPEAT)
+            for _ in range(max(psteps // 10, 8)):
+                step()
+            torch.cuda.synchronize()
+            chunks.append({k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in handle.read_profile().items()})
         handle.set_profiling(False)
         hot = ("vote", "stats", "gimage", "grad")
-        per_kernel = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof.items()}  # us per launch
+        per_kernel = {k: float(np.median([c[k] for c in chunks])) for k in chunks[0]}  # us per launch
         single = {k: (ms / cnt * 1e3 if cnt else 0.0) for k, (ms, cnt) in prof_single.items()}
         kernels = {}
         for k in hot:
@@ -270,7 +272,7 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
         out["kernels"] = kernels
         out["dominant"] = max((k for k in hot if k in kernels), key=lambda k: kernels[k]["launch_us"])
         out["profile_method"] = ("HIP events on the launch stream; each bracket of a hot class holds %d back-to-back launches of the "
-                                 "kernel (instrumented pass after the timed region, same inputs)" % REPEAT)
+                                 "kernel (instrumented passes after the timed region, same inputs; median of 5 passes)" % REPEAT)
     if keep_inputs:
         out["_inputs"] = (cfg, ev, motion)
     handle.close()

@@ -39,7 +39,7 @@ if os.path.exists(f):
                   "# reference (torch-CPU fp64, BASELINE.md): 126 / 231 ms plain, 294 / 1098 ms Burgers (value+grad / hvp)\n")
         out.writelines(lines)
 short = {"k_vote": "vote", "k_stats": "stats", "k_gimage": "gimage", "k_grad": "grad", "k_finish": "finish", "k_finish_deferred": "finish",
-         "k_stats_gimage_gm": "stats", "k_blur_stats_gimage_gm": "stats", "k_blur_stats_var": "stats", "k_gimage_blur_adj_var": "gimage"}
+         "k_stats_gimage_gm": "stats", "k_blur_stats_gimage_gm": "stats", "k_blur_stats_var": "stats", "k_gimage_blur_adj_var": "gimage", "k_blur_stats_adj_var": "stats"}
 for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
     f = os.path.join(src, "refresh", "pmc_%s_raw.json" % wl)
     if not os.path.exists(f):
