@@ -96,6 +96,23 @@ def test_cfg4_full_size_burgers_voxel():
     check("cfg4 2M 260x346 voxel T=10 sigma 1", h, res, grad, ref, bound, n_amb)
 
 
+def test_cfg4_size_voxel_plain_variance():
+    """cfg4's batch with the un-blurred variance: the 1024-thread owned voxel K3 with the statistics inside its launch
+    (kFoldStatsInside), which no BASELINE configuration reaches at this workgroup size."""
+    size, n, Tn = (260, 346), 2_000_000, 10
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=48)
+    f0 = E.utils.generate_smooth_flow(size, 20, seed=1048)
+    voxel = orc.construct_dense_flow_voxel(f0 / 20.0, Tn, "burgers", "middle") * 20.0
+    h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
+    assert h.batch_info()["owned_groups"]
+    desc = E.make_descriptor("image_variance", "dense-flow-voxel", sigma=0.0, time_bin=Tn)
+    ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=0)
+    bound, n_amb = ambiguity_bound(ev, voxel, "dense-flow-voxel", size, raw_image_grad(ref, 0))
+    for rep in range(2):
+        res, grad = h.evaluate(desc, voxel)
+        check(f"cfg4-size 2M voxel T=10 plain variance #{rep}", h, res, grad, ref, bound, n_amb)
+
+
 def test_cfg5_shard_full_size_with_gradient():
     """One rank's share of cfg5: 2.5M events on 720x1280 (2.7 events per pixel), dense flow, variance + gradient."""
     size, n = (720, 1280), 2_500_000
