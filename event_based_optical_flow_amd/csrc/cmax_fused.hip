@@ -676,21 +676,26 @@ __device__ __forceinline__ void write_result_variance_agent(const ObjParams &op,
     result[5] = 0.0;
 }
 
-// loss and per-reference-time contrasts -> result[0..5]
-__device__ void write_result(const ObjParams &op, const double *stat, double *__restrict__ result) {
+// loss and per-reference-time contrasts -> result[0..5].  WAVE: called by a whole converged wave (the accumulators of a slot
+// are gathered in ONE round trip instead of a serial walk over their cache lines); its first lane writes.
+template <bool WAVE = false>
+__device__ __forceinline__ void write_result(const ObjParams &op, const double *stat, double *__restrict__ result) {
     const double npix = region_pixels(op.H, op.W, op.omit);
-    const double v_orig = op.normalized ? orig_value(op, stat) : 0.0;
+    const double v_orig = op.normalized ? orig_value<WAVE>(op, stat) : 0.0;
+    const bool writer = !WAVE || (threadIdx.x & (kWave - 1)) == 0;
     double loss = 0.0;
     for (int k = 0; k < op.n_ref; ++k) {
         double acc[2];
-        stat_sum(stat, k, op.nsub, acc);
+        stat_sum<WAVE>(stat, k, op.nsub, acc);
         const double v = contrast_value(op.cost, acc, npix, nullptr);
-        result[1 + k] = v;
+        if (writer) result[1 + k] = v;
         if (!op.normalized) loss += op.mult[k] * (op.minimize ? -v : v);
         else loss += op.mult[k] * (op.minimize ? v_orig / v : v / v_orig);
     }
-    result[0] = op.negate ? -loss : loss;
-    result[5] = v_orig;
+    if (writer) {
+        result[0] = op.negate ? -loss : loss;
+        result[5] = v_orig;
+    }
 }
 
 template <int COST>
@@ -1687,13 +1692,14 @@ static int stat_blocks(const cmax_handle_s *h) {
 // statistics of `img` -> stat[slot] (accumulators zeroed by the K1 launch); optionally zero `zero_img`
 static int stat_subs(const cmax_handle_s *h) {
     if (h->deterministic) return kStatSub;
-    // one 128-byte line per sub-accumulator: every consumer (each K3 workgroup) gathers nsub lines at its head, so few of
-    // them; 8 lines keep the atomics of even 1200 image-kernel workgroups at ~150 per line (cfg3 K3 21.1 us with 25 lines,
-    // 18.7 with 8; the image kernel 5.6 either way)
-    int n = stat_blocks(h) / 12;
+    // one 128-byte line per sub-accumulator (same-line atomics serialise).  Their readers are ONE wave per K3 workgroup (and
+    // only for a normalised cost) and the wave that writes the loss, each with one load per lane -- when every wave of K3
+    // gathered them at its head, more than 8 lines cost K3 more than they saved K2 (cfg3 K3 18.7 -> 21.1 us with 25 lines).
+    // 16 lines: cfg3's image kernel (1200 workgroups) 6.0 -> 5.65 us, cfg4's (363) 6.5 -> 5.95.
+    int n = stat_blocks(h) / 6;
     static const int forced = getenv("CMAX_NSUB") ? atoi(getenv("CMAX_NSUB")) : 0;  // tuning only
     if (forced > 0) return forced < kStatSub ? forced : kStatSub;
-    return n < 4 ? 4 : (n > 8 ? 8 : n);
+    return n < 4 ? 4 : (n > 16 ? 16 : n);
 }
 
 // zero_extra: optional buffer of n_extra floats (16-byte aligned, n_extra % 4 == 0) cleared by the same launch
