@@ -17,10 +17,11 @@
 //                   k_blur_stats_adj_var (variance with blur and a gradient: ONE kernel, the mean comes from K1's vote sums;
 //                   value-only / multi-GPU: k_blur_stats_var + k_gimage_blur_adj_var),
 //                   k_stats_gimage_gm / k_blur_stats_gimage_gm (gradient magnitude: statistics + the
-//                   unscaled G = dL/dIWE, blurs included).  They also clear the OTHER vote buffer for
+//                   G = dL/dIWE, blurs included).  They also clear the OTHER vote buffer for
 //                   the next evaluation (double buffering: no memset in the steady state) and the
 //                   flow-gradient buffer, with write-through stores.  Plain variance needs no G image:
-//                   K3 forms G = coef * (IWE - mean) on the fly
+//                   K3 gathers the raw image (the mean cancels in the gather's differences except at the
+//                   edge of the region); on owned groups its K2 even runs INSIDE the K3 launch (kFoldStatsInside)
 //   K3  k_grad      per event: re-warp, gather G at the 4 corners -> dL/d(x',y') -> motion gradient
 //                   (2-DoF: per-segment partials, for the plain variance together with the image
 //                   statistics so that K2 is not launched at all; dense: runs of equal source pixel
@@ -48,8 +49,8 @@
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
 //   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
-//   CMAX_STAT_SWEEPS=n       ... and how many 4-pixel sweeps each of those workgroups makes (fewer, longer workgroups)
 //   CMAX_NO_STATS_INSIDE=1   plain variance on owned groups: k_stats as a launch of its own instead of inside K3's
+//   CMAX_STAT_SWEEPS=n       statistics inside K3's launch: 4-pixel sweeps per statistics workgroup (fewer, longer workgroups)
 //   CMAX_NO_FUSED_BLURVAR=1  blurred variance: k_blur_stats_var + k_gimage_blur_adj_var instead of k_blur_stats_adj_var
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
 //   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
