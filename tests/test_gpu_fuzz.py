@@ -459,3 +459,51 @@ def test_large_sensor_takes_the_global_tile_path(model, time_bin):
         ref4 = orc.objective(keep, motion4, "dense-flow-voxel", (H, W), cost="image_variance", sigma=0)
         l4 = E.ContrastObjective(h, "dense-flow-voxel", cost="image_variance", sigma=0)(torch.as_tensor(motion4, device="cuda"))
         assert abs(l4.item() - ref4["loss"]) <= 1e-4 * abs(ref4["loss"]), (l4.item(), ref4["loss"])
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CMAX_FUZZ_OWNED_SEEDS", "4"))))
+def test_random_owned_groups_configuration_against_oracle(seed):
+    """The same differential test at batch sizes that reach the group-aligned work list (>= 522k events, <= 7 events per
+    pixel): owned-groups K3, the statistics inside its launch (plain variance), the one-kernel blurred variance with the
+    mean from K1's vote sums, normalised costs on the same list -- sensor size, padding, flow magnitude (votes that leave
+    the image), time bins, direction and omit_boundary drawn per seed.  CMAX_FUZZ_OWNED_SEEDS=n runs more draws."""
+    from _border import ambiguity_bound, raw_image_grad
+
+    rng = np.random.default_rng(7000 + seed)
+    H, W = int(rng.integers(270, 360)), int(rng.integers(330, 420))
+    pad = int(rng.choice([0, 0, 2]))
+    n = int(rng.integers(530_000, 640_000))
+    model = ["dense-flow", "dense-flow-voxel"][seed % 2]
+    cost = ["image_variance", "image_variance", "normalized_image_variance", "gradient_magnitude"][(seed // 2) % 4]
+    sigma = int(rng.integers(0, 2))
+    omit = bool(rng.integers(0, 2))
+    direction = ["minimize", "maximize", "natural"][int(rng.integers(0, 3))]
+    mag = float(rng.choice([3.0, 15.0, 45.0]))
+    ev = E.utils.generate_events(n, H, W, 0.1, 0.16, seed=seed + 500)
+    f0 = E.utils.generate_smooth_flow((H, W), mag, grid=4, seed=seed + 17)
+    T = 0
+    if model == "dense-flow":
+        motion = f0
+    else:
+        T = int(rng.choice([2, 5]))
+        motion = np.stack([f0 * (1.0 + 0.07 * k) for k in range(T)])
+    size = (H, W)
+    h = E.CMaxHandle(size, pad).set_events(ev, time_bin=T) if T else E.CMaxHandle(size, pad).set_events(ev)
+    info = dict(H=H, W=W, pad=pad, n=n, model=model, cost=cost, sigma=sigma, omit=omit, direction=direction, mag=mag, T=T)
+    assert h.batch_info()["owned_groups"], info
+    desc = E.make_descriptor(cost, model, direction=direction, sigma=float(sigma), omit_boundary=omit, time_bin=T)
+    ref = orc.objective(ev, motion, model, size, cost=cost, sigma=sigma, outer_padding=pad, omit_boundary=omit, direction=direction)
+    tol = 1e-4
+    for rep in range(2):
+        res, grad = h.evaluate(desc, motion)
+        assert abs(res[0].item() - ref["loss"]) <= tol * abs(ref["loss"]), (info, rep, res[0].item(), ref["loss"])
+        g = grad.double().cpu().numpy()
+        gmax = np.abs(ref["grad"]).max()
+        err = np.abs(g - ref["grad"])
+        if err.max() > tol * gmax:
+            # events within fp32 rounding of a bilinear cell border (tests/_border.py): a few entries, never a pattern
+            n_over = int((err > tol * gmax).sum())
+            assert n_over <= max(8, int(2e-5 * err.size)), (info, rep, n_over, err.max() / gmax)
+            if pad == 0 and not cost.startswith("normalized"):  # ... and each within the bound of its border events
+                bound, _ = ambiguity_bound(ev, motion, model, size, raw_image_grad(ref, sigma))
+                assert ((err - 1.01 * bound).max()) <= tol * gmax, (info, rep, err.max() / gmax)
