@@ -819,7 +819,27 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
     const int la = threadIdx.x / kGmTileW, lb = threadIdx.x - la * kGmTileW;  // pixel of this thread inside the tile
     const int i = r0 + 2 + la, j = c0 + 2 + lb;
     double v[2] = {0.0, 0.0};
-    if (i < H && j < W) {
+    // A tile whose pixels all have their 3 x 3 neighbourhood inside Omega (every tile but those along the border): the
+    // transpose of the Sobel pair applied to its own responses is ONE 5 x 5 stencil on the image,
+    //   Sobel^T Sobel = A(dr) W(dc) + W(dr) A(dc),  A = autocorrelation of (-1, 0, 1) = (-1, 0, 2, 0, -1),  W = that of (1, 2, 1) = (1, 4, 6, 4, 1)
+    // -- 25 LDS reads per pixel instead of the 108 of the 18 responses below (workgroup-uniform branch; k_stats_gimage_gm of
+    // cfg3 5.7 -> see profiles/r02_ablation.txt).
+    const int ri = (int)blockIdx.x / tiles_w * kGmTileH, ci = tc * kGmTileW;
+    const bool interior = ri >= i0 + 1 && ri + kGmTileH - 1 <= H - i0 - 2 && ci >= i0 + 1 && ci + kGmTileW - 1 <= W - i0 - 2;
+    if (interior) {
+        float t5[5][5];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) t5[a][b] = tile[la + a][lb + b];
+        const float gxc = ((t5[3][1] + 2.f * t5[3][2] + t5[3][3]) - (t5[1][1] + 2.f * t5[1][2] + t5[1][3])) * 0.125f;
+        const float gyc = ((t5[1][3] + 2.f * t5[2][3] + t5[3][3]) - (t5[1][1] + 2.f * t5[2][1] + t5[3][1])) * 0.125f;
+        const float r_outer = -2.f * (t5[0][0] + t5[0][4] + t5[4][0] + t5[4][4]) - 4.f * (t5[0][1] + t5[0][2] + t5[0][3] + t5[4][1] + t5[4][2] + t5[4][3]);
+        const float r_mid = -4.f * (t5[1][0] + t5[1][4] + t5[3][0] + t5[3][4]) + 8.f * (t5[1][2] + t5[3][2]);
+        const float r_centre = -4.f * (t5[2][0] + t5[2][4]) + 8.f * (t5[2][1] + t5[2][3]) + 24.f * t5[2][2];
+        G[(int64_t)i * W + j] = gscale * 0.125f * (r_outer + r_mid + r_centre);
+        v[0] = (double)(gxc * gxc + gyc * gyc);
+    } else if (i < H && j < W) {
         // Sobel/8 responses of the 3x3 neighbourhood (the centre one also feeds the statistics)
         float gx[3][3], gy[3][3];
 #pragma unroll

@@ -113,15 +113,24 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=[c[0] + "-" + c[1] for c in CASES])
 def test_time_sliced_objective_world2(case):
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    for attempt in range(3):  # the free port can be taken again before rank 0's store binds it: then both ranks die at once
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = []
+        try:
+            got = [q.get(timeout=120) for _ in range(2)]
+        except Exception:  # queue.Empty: a rank did not get as far as its result
+            pass
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+        if len(got) == 2 and all(p.exitcode == 0 for p in procs):
+            break
+        assert attempt < 2, [p.exitcode for p in procs]
     cost, model, motion = case
     size = (24, 32)
     ev = E.utils.generate_events(3001, size[0], size[1], 0.0, 0.05, seed=7)

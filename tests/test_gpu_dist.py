@@ -36,14 +36,20 @@ def rel_max(a, b):
 
 @pytest.fixture(scope="module")
 def world1_nccl():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    for attempt in range(5):  # the port the kernel just handed out can be taken again before the store binds it (seen once in 30 runs)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ["MASTER_PORT"] = str(port)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            break
+        except Exception:  # torch.distributed.DistNetworkError: address already in use
+            if attempt == 4:
+                raise
     yield
     dist.destroy_process_group()
 
