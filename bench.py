@@ -189,8 +189,14 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
         motion_dev = torch.from_numpy(np.asarray(motion)).to(dev).float().contiguous()
     desc = E.make_descriptor(cfg["cost"], cfg["model"], sigma=cfg["sigma"], time_bin=T)
 
+    # one evaluation = one prepared library call (outputs allocated once, pointers resolved once: what a solver loop in C
+    # would do; `evaluate` spends ~6 us per call in Python, which on a busy host is the difference between a GPU-bound and a
+    # host-bound 17 us evaluation -- profiles/r02_ablation.txt)
+    call, res, grad = sliced.prepare(desc, motion_dev, want_grad=True)
+
     def step():
-        return sliced.evaluate(desc, motion_dev, want_grad=True)
+        call()
+        return res, grad
 
     def sync_all():
         if world > 1:
@@ -199,6 +205,14 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
 
     for _ in range(warmup):
         res, grad = step()
+    # clock ramp: a process that starts on an idle GPU measures its first ~second in a lower power state (the first bench process
+    # on a fresh box: kernels 6-7 % slower through all 25 windows -- 0.1 s of GPU work in total -- than the same command run
+    # again; profiles/r02_ablation.txt).  Untimed evaluations until `--ramp` seconds have passed; the K timed steps follow.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp:
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
     times = []
     for _ in range(windows):
         sync_all()
@@ -307,6 +321,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--windows", type=int, default=25, help="timed windows of --steps evaluations; the median window is reported")
+    ap.add_argument("--ramp", type=float, default=1.5, help="seconds of untimed evaluations after the warm-up steps, before the timed "
+                    "windows (lets an idle GPU reach its clocks; 0 = none)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations (cfg3, cfg4, cfg5) reported under `also`")
@@ -384,8 +400,10 @@ def main():
                        "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}", "deterministic": bool(args.deterministic),
                        "collectives": None if world == 1 else main_res["collectives"] + ": all-reduce(IWE) + all-reduce(grad) per evaluation",
                        "rccl": main_res.get("rccl")},
-            "timing": dict(main_res["window_ms_per_step"], statistic="median window; every window = `steps` evaluations between barrier + "
-                                                                      "synchronize on both sides, max over ranks"),
+            "timing": dict(main_res["window_ms_per_step"], ramp_s=args.ramp,
+                           statistic="median window; every window = `steps` evaluations between barrier + synchronize on both sides, max "
+                                     "over ranks; `ramp_s` seconds of untimed evaluations precede the windows (GPU clocks); one evaluation = "
+                                     "one prepared library call (CMaxHandle.prepare)"),
             "roofline": {"bound": "hbm",
                          "scope": "one evaluation (SURVEY 8d: B = 24 N + 16 HW + B_model algorithmic bytes / median step time), per GPU",
                          "achieved": main_res["evaluation_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -172,6 +172,29 @@ class CMaxHandle:
                                        grad.data_ptr() if grad is not None else None, F._stream()))
         return result, grad
 
+    def prepare(self, desc: CmaxObjective, motion, want_grad: bool = True, dist: bool = False):
+        """A prepared cmax_objective (dist: cmax_objective_dist) call for an inner loop that evaluates the SAME motion
+        buffer again and again (an optimiser updating it in place, a benchmark): outputs allocated once, pointers
+        resolved once.  Returns (call, result, grad); `call()` enqueues one evaluation on the current stream and
+        overwrites result / grad.  `evaluate` spends ~6 us per call in Python (two allocations, tensor checks) -- as
+        much as the three launches of a 1M-event 2-DoF evaluation leave the host to spare (profiles/r02_ablation.txt)."""
+        m = self._motion32(motion)
+        result = torch.empty(8, dtype=torch.float64, device=self.device)
+        grad = None
+        if want_grad:
+            grad = (torch.empty(2, dtype=torch.float64, device=self.device) if desc.model == _lib.MODEL_2DOF
+                    else torch.empty(tuple(m.shape), dtype=torch.float32, device=self.device))
+        fn = self._lib.cmax_objective_dist if dist else self._lib.cmax_objective
+        h, dref, mp, rp, gp, stream = self._h, ctypes.byref(desc), m.data_ptr(), result.data_ptr(), grad.data_ptr() if grad is not None else None, F._stream
+
+        def call():
+            rc = fn(h, dref, mp, rp, gp, stream())
+            if rc:
+                check(rc)
+
+        call.keepalive = (m, desc, result, grad)  # the pointers above stay valid as long as the callable lives
+        return call, result, grad
+
     def hvp(self, desc: CmaxObjective, motion, tangent) -> torch.Tensor:
         """Exact Hessian-vector product H @ tangent of the objective w.r.t. the motion (cmax_objective_hvp):
         what torch.autograd.functional.vhp gives the reference's Newton-CG.  Returns fp64 [2] (2-DoF) or

@@ -101,6 +101,21 @@ class TimeSlicedObjective:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def prepare(self, desc, motion, want_grad: bool = True):
+        """(call, result, grad): `call()` = one evaluation of the whole batch with preallocated outputs (CMaxHandle.prepare);
+        the torch-collectives fallback and stand-in locals get a closure over `evaluate` that copies into the same buffers."""
+        if hasattr(self.local, "prepare") and (self.world_size == 1 or self.collectives.startswith("in-library")):
+            return self.local.prepare(desc, motion, want_grad, dist=self.world_size > 1)
+        result, grad = self.evaluate(desc, motion, want_grad)
+
+        def call():
+            r, g = self.evaluate(desc, motion, want_grad)
+            result.copy_(r)
+            if g is not None:
+                grad.copy_(g)
+
+        return call, result, grad
+
     def evaluate(self, desc, motion, want_grad: bool = True):
         if self.world_size == 1 and hasattr(self.local, "evaluate"):
             return self.local.evaluate(desc, motion, want_grad)  # no exchange step: one cmax_objective call

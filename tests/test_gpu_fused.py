@@ -450,3 +450,21 @@ def test_dropped_events_are_counted_and_reported(caplog):
     assert abs(res[0].item() - ref["loss"]) <= 1e-3 * abs(ref["loss"])
     h.set_events(ev[keep])
     assert h.batch_info()["dropped"] == 0
+
+
+def test_prepared_call_equals_evaluate_and_follows_the_motion_buffer():
+    """CMaxHandle.prepare: one allocation, many evaluations of a motion buffer that is updated in place."""
+    size = (60, 80)
+    ev = E.utils.generate_events(20000, size[0], size[1], 0.0, 0.05, seed=12)
+    h = E.CMaxHandle(size).set_events(ev)
+    desc = E.make_descriptor("image_variance", "2d-translation")
+    theta = torch.tensor([4.0, -3.0], dtype=torch.float32, device="cuda")
+    call, res, grad = h.prepare(desc, theta)
+    for t in ([4.0, -3.0], [-7.5, 2.25]):
+        theta.copy_(torch.tensor(t, dtype=torch.float32))
+        call()
+        r2, g2 = h.evaluate(desc, theta)
+        ref = orc.objective(ev, np.array(t), "2d-translation", size, cost="image_variance", sigma=0)
+        assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+        assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
+        assert abs(res[0].item() - r2[0].item()) <= 1e-6 * abs(r2[0].item()) and rel_max(grad.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
