@@ -92,6 +92,11 @@ def test_objective_dist_world1_rccl(world1_nccl, model, cost, sigma, Tn):
     ref = orc.objective(ev, motion, model, size, cost=cost, sigma=int(sigma))
     assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_max(grad_d.cpu().numpy(), ref["grad"]) <= TOL
+    # the prepared form of the same call (what bench.py runs per step at N > 1)
+    call, res_p, grad_p = h.prepare(desc, motion, dist=True)
+    call()
+    torch.cuda.synchronize()
+    assert abs(res_p[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item()) and rel_max(grad_p.cpu().numpy(), grad.cpu().numpy()) <= 2e-6
     # the raw collective entry: a 1-rank all-reduce leaves the buffer as it is
     t = torch.arange(8, dtype=torch.float64, device="cuda")
     h.comm_allreduce(t, "min")
