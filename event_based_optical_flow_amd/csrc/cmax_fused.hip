@@ -449,12 +449,18 @@ __device__ __forceinline__ int segment_of_block(int nseg, unsigned bx = blockIdx
 
 struct Window {
     int r0, c0, h, w;  // top-left corner in the padded image, extent (clipped to the image and to LDS)
-    int sh;            // LDS row stride = 1 << sh (power of two: a shift instead of an integer multiply per vote)
+    int stride;        // LDS row stride in words: odd (window_stride), so that the rows of a window start in different banks
     bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
 };
 // how K3 obtains dL/dIWE: from a materialised G image; folded G = c2 (IWE - mu) with the statistics K2 left in
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
+// Row stride of an LDS window of width w.  With a power-of-two stride (the first version: a shift per index) the bank of a
+// cell is its COLUMN modulo 32 whatever its row -- a 20-pixel-wide window used 20 of the 32 banks, and the two rows of a
+// 2 x 2 footprint always collided (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.55-0.70 in K1 and K3, profiles/r02_sq_*).  An odd
+// stride walks the banks row by row; the index costs one v_mad_u32_u24 instead of a shift + add.
+__host__ __device__ inline int window_stride(int w) { return (w < 15 ? 15 : w) | 1; }
+
 constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3;  // kFoldScale: G image stored without its chain factor
 // kFoldStatsInside: kFoldStats for a plain (not normalised) variance whose K2 runs INSIDE the K3 launch -- the first
 // RefArgs::stat_blocks workgroups of the grid are k_stats (they also write the loss), the others gather; nothing in the
