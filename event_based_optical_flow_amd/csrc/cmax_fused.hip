@@ -406,13 +406,13 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
         dx = ev.rx[i];
         dy = ev.ry[i];
     }
-    w.src = ix * wp.W + iy;
+    w.src = (int)__umul24((unsigned)ix, (unsigned)wp.W) + iy;  // 12-bit x 13-bit: v_mul_u32_u24 (full rate; v_mul_lo_u32 runs at a quarter)
     if (MODEL == CMAX_MODEL_2DOF) {
         dx = fmaf(w.dt, th0, dx);  // x' = x + dt*theta0, src/warp.py:506-515
         dy = fmaf(w.dt, th1, dy);
     } else if (MODEL == CMAX_MODEL_DENSE || MODEL == CMAX_MODEL_VOXEL) {
         const int hw = wp.H * wp.W;
-        if (MODEL == CMAX_MODEL_VOXEL) w.src += (int)(pk >> 24) * 2 * hw;
+        if (MODEL == CMAX_MODEL_VOXEL) w.src += (int)(pk >> 24) * 2 * hw;  // (2 HW can exceed 24 bits: a full 32-bit multiply)
         // uniform base + unsigned 32-bit BYTE offset: one address instruction per event and a `global_load_dword v, voff, s[base]`
         // per channel, instead of 64-bit per-lane pointer arithmetic (the field is < 4 GiB: checked by the host)
         const unsigned off = (unsigned)w.src * 4u;
@@ -455,6 +455,11 @@ struct Window {
 // how K3 obtains dL/dIWE: from a materialised G image; folded G = c2 (IWE - mu) with the statistics K2 left in
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
+// Linear index of pixel (r, c) of an image that is W wide, r >= 0: one full-rate v_mad_u32_u24 (rows and widths are < 2^13;
+// a 64-bit r * W + c is a quarter-rate v_mad_u64_u32, a 32-bit one a quarter-rate v_mul_lo_u32 -- and the event kernels are
+// VALU-bound on the large configurations: SQ_ACTIVE_INST_VALU x 8 waves ~ 0.8 of the SIMD cycles in K1 / K3 of cfg3).
+__device__ __forceinline__ int pix_index(int r, int c, int W) { return (int)__umul24((unsigned)r, (unsigned)W) + c; }
+
 // Row stride of an LDS window of width w.  With a power-of-two stride (the first version: a shift per index) the bank of a
 // cell is its COLUMN modulo 32 whatever its row -- a 20-pixel-wide window used 20 of the 32 banks, and the two rows of a
 // 2 x 2 footprint always collided (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.55-0.70 in K1 and K3, profiles/r02_sq_*).  An odd
