@@ -406,7 +406,7 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
         dx = ev.rx[i];
         dy = ev.ry[i];
     }
-    w.src = (int)__umul24((unsigned)ix, (unsigned)wp.W) + iy;  // 12-bit x 13-bit: v_mul_u32_u24 (full rate; v_mul_lo_u32 runs at a quarter)
+    w.src = (int)__umul24((unsigned)ix, (unsigned)wp.W & 0xFFFFFFu) + iy;  // 12-bit x 13-bit: v_mul_u32_u24 (full rate; v_mul_lo_u32 runs at a quarter)
     if (MODEL == CMAX_MODEL_2DOF) {
         dx = fmaf(w.dt, th0, dx);  // x' = x + dt*theta0, src/warp.py:506-515
         dy = fmaf(w.dt, th1, dy);
@@ -458,7 +458,7 @@ struct Window {
 // Linear index of pixel (r, c) of an image that is W wide, r >= 0: one full-rate v_mad_u32_u24 (rows and widths are < 2^13;
 // a 64-bit r * W + c is a quarter-rate v_mad_u64_u32, a 32-bit one a quarter-rate v_mul_lo_u32 -- and the event kernels are
 // VALU-bound on the large configurations: SQ_ACTIVE_INST_VALU x 8 waves ~ 0.8 of the SIMD cycles in K1 / K3 of cfg3).
-__device__ __forceinline__ int pix_index(int r, int c, int W) { return (int)__umul24((unsigned)r, (unsigned)W) + c; }
+__device__ __forceinline__ int pix_index(int r, int c, int W) { return (int)__umul24((unsigned)r, (unsigned)W & 0xFFFFFFu) + c; }
 
 // Row stride of an LDS window of width w.  With a power-of-two stride (the first version: a shift per index) the bank of a
 // cell is its COLUMN modulo 32 whatever its row -- a 20-pixel-wide window used 20 of the 32 banks, and the two rows of a
