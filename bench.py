@@ -293,6 +293,32 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     return out
 
 
+def pin_to_gpu_numa_node(dev_index):
+    """Best effort: run this process on the CPUs of the NUMA node its GPU hangs off (sysfs).  The launch thread of a process
+    that lands on the far socket reaches the GPU's doorbell and queue across the inter-socket link: of 18 unpinned / far-node
+    runs of the default command 3 measured 19 us per cfg2 evaluation instead of 16.5-17.5, of 14 runs pinned to the GPU's node
+    none (profiles/r02_ablation.txt).  Returns a description for the JSON line, or None when the topology is not exposed."""
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)  # never widen what the launcher allowed
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return f"NUMA node {node} of GPU {bdf} ({len(cpus)} CPUs)"
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -321,6 +347,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--windows", type=int, default=25, help="timed windows of --steps evaluations; the median window is reported")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the CPUs of its GPU's NUMA node")
     ap.add_argument("--ramp", type=float, default=1.5, help="seconds of untimed evaluations after the warm-up steps, before the timed "
                     "windows (lets an idle GPU reach its clocks; 0 = none)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
@@ -358,6 +385,7 @@ def main():
             dist.init_process_group(backend="gloo")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    host_affinity = None if args.no_pin else pin_to_gpu_numa_node(dev.index)
 
     main_res = run_workload(args.workload, args, rank, world, dev, args.steps, args.warmup, args.windows, keep_inputs=True)
     cfg, ev, motion = main_res.pop("_inputs")
@@ -400,7 +428,7 @@ def main():
                        "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}", "deterministic": bool(args.deterministic),
                        "collectives": None if world == 1 else main_res["collectives"] + ": all-reduce(IWE) + all-reduce(grad) per evaluation",
                        "rccl": main_res.get("rccl")},
-            "timing": dict(main_res["window_ms_per_step"], ramp_s=args.ramp,
+            "timing": dict(main_res["window_ms_per_step"], ramp_s=args.ramp, host_affinity=host_affinity,
                            statistic="median window; every window = `steps` evaluations between barrier + synchronize on both sides, max "
                                      "over ranks; `ramp_s` seconds of untimed evaluations precede the windows (GPU clocks); one evaluation = "
                                      "one prepared library call (CMaxHandle.prepare)"),
