@@ -293,6 +293,47 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     return out
 
 
+def graph_replay_rate(cfg, ev, motion, dev, steps, windows):
+    """The same evaluations replayed from a hipGraph (torch.cuda.CUDAGraph over the library's launches): `steps` evaluations
+    per replay, so the host does nothing between them.  Reported NEXT TO `value`, never as it: an optimiser reads loss and
+    gradient after every evaluation and cannot run this way -- the figure shows what the GPU does when the host is out of
+    the picture (on a shared node the eager loop's 10 us of enqueue work per 17 us evaluation is what neighbours disturb)."""
+    import torch
+
+    import event_based_optical_flow_amd as E
+
+    try:
+        handle = E.CMaxHandle((cfg["H"], cfg["W"]))
+        handle.set_events(torch.from_numpy(ev).to(dev))
+        desc = E.make_descriptor(cfg["cost"], cfg["model"], sigma=cfg["sigma"])
+        m = torch.from_numpy(np.asarray(motion)).to(dev).float().contiguous()
+        call, res, grad = handle.prepare(desc, m)
+        k = steps + (steps & 1)  # even: the handle's double-buffered images end a replay where they began it
+        for _ in range(50):
+            call()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(k):
+                call()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(windows):
+            t0 = time.perf_counter()
+            g.replay()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / k)
+        t = float(np.median(times))
+        out = {"ms_per_step": t * 1e3, "value": cfg["n"] / t, "evaluations_per_graph": k, "windows": windows,
+               "loss": float(res[0].item()), "note": "hipGraph replay of the same launches; not the way a solver can call the path"}
+        handle.close()
+        return out
+    except Exception as e:  # capture not available / refused: report, never fail the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def pin_to_gpu_numa_node(dev_index):
     """Best effort: run this process on the CPUs of the NUMA node its GPU hangs off (sysfs).  The launch thread of a process
     that lands on the far socket reaches the GPU's doorbell and queue across the inter-socket link: of 18 unpinned / far-node
@@ -446,6 +487,8 @@ def main():
         }
         if also:
             out["also"] = also
+        if world == 1 and not args.deterministic and cfg["model"] == "2d-translation":
+            out["graph_replay"] = graph_replay_rate(cfg, ev, motion, dev, max(args.steps, 50), min(args.windows, 11))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ev, motion)
             tc = cpu_baseline_torch(cfg, ev, motion)
