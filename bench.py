@@ -53,6 +53,16 @@ WORKLOADS = {
     # cfg5 as BASELINE states it: ONE 20M-event batch, time-sliced over the N ranks (strong scaling)
     "cfg5_strong": dict(H=720, W=1280, n=20_000_000, model="dense-flow", cost="image_variance", sigma=0.0, strong=True,
                         desc="cfg5: 20M synthetic events, 1280x720, dense flow, image_variance, time-sliced over the ranks"),
+    # out of the 256 MiB Infinity Cache: the packed stream alone is 512 MB and is read twice per evaluation (K1, K3), so HBM
+    # -- not the cache -- feeds the kernels.  Events are drawn on the device (torch.Generator): 2 GB of fp64 [n, 4] never cross PCIe.
+    "hbm": dict(H=720, W=1280, n=64_000_000, model="dense-flow", cost="image_variance", sigma=0.0, device_gen=True,
+                desc="hbm: 64M synthetic events, 1280x720, dense flow, image_variance (512 MB packed stream: larger than the Infinity Cache)"),
+    # SURVEY 8(d) second rows of the headline: the YAMLs' blur, and a sharp image (2500 dots warped with their true motion --
+    # what an optimiser converges to; the friendliest case for LDS / L2 atomics is the uniform stream above)
+    "cfg2_sigma1": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=1.0,
+                        desc="cfg2 with the YAMLs' blur: 1M uniform events, 346x260, 2-DoF, image_variance, sigma 1"),
+    "cfg2_structured": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, structured=True,
+                            desc="cfg2 on a sharp image: 1M events of 2500 dots moving with theta, 346x260, 2-DoF, image_variance"),
 }
 KERNEL_NAMES = {"vote": "k_vote (K1 warp + bilinear vote)", "grad": "k_grad (K3 gather + gradient)", "stats": "k_stats* (K2 image statistics)",
                 "gimage": "k_gimage* (K2b dL/dIWE)", "finish": "k_finish* (final reduction)", "comm": "RCCL all-reduce"}
@@ -88,6 +98,17 @@ def measured_traffic(workload: str, kernel: str):
     return None
 
 
+def traffic_source(workload: str):
+    """Where `traffic` comes from: the committed counter summary of an EARLIER run of the same workload, not this run."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)), reverse=True)
+    if not paths:
+        return None
+    return ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload, tools/prof_pmc.sh; "
+            "replayed, not measured in this run)" % os.path.relpath(paths[0], ROOT))
+
+
 def make_inputs(cfg, rank, world, seed=46, structured=False):
     """This rank's time slice [rank, rank + 1) * period / world of the batch (host fp64 [n, 4]) and the motion."""
     import event_based_optical_flow_amd as E
@@ -96,8 +117,18 @@ def make_inputs(cfg, rank, world, seed=46, structured=False):
     n = cfg["n"] // world if cfg.get("strong") else cfg["n"]
     period = 0.05
     t0, t1 = rank * period / world, (rank + 1) * period / world
-    if structured and cfg["model"] == "2d-translation":
+    if (structured or cfg.get("structured")) and cfg["model"] == "2d-translation":
         ev = E.utils.generate_structured_events(n, H, W, (12.3, -7.7), n_dots=2500, tmin=t0, tmax=t1, seed=seed + rank)
+    elif cfg.get("device_gen"):
+        import torch
+
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed + rank)
+        ev = torch.empty((n, 4), dtype=torch.float64, device="cuda")
+        ev[:, 0] = torch.randint(0, H, (n,), generator=g, device="cuda")
+        ev[:, 1] = torch.randint(0, W, (n,), generator=g, device="cuda")
+        ev[:, 2] = torch.sort(torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * (t1 - t0) + t0).values
+        ev[:, 3] = torch.randint(0, 2, (n,), generator=g, device="cuda")
     else:
         ev = E.utils.generate_events(n, H, W, tmin=t0, tmax=t1, seed=seed + rank)
     T = 0
@@ -109,6 +140,33 @@ def make_inputs(cfg, rank, world, seed=46, structured=False):
         T = 10
         motion = None  # built on the GPU from the t0 flow
     return ev, motion, T
+
+
+def host_cpu_info():
+    """CPU model, sockets, physical cores and logical CPUs of this host (/proc/cpuinfo), for the CPU rows of the line."""
+    info = {"model": None, "sockets": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
+    try:
+        cores, sockets, phys, core = set(), set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            key, _, val = ln.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "model name" and info["model"] is None:
+                info["model"] = val
+            elif key == "physical id":
+                phys = val
+                sockets.add(val)
+            elif key == "core id":
+                core = val
+            elif not key and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        info["sockets"] = len(sockets) or None
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
+    return info
 
 
 def cpu_baseline(cfg, ev, motion, budget_s=12.0):
@@ -125,34 +183,78 @@ def cpu_baseline(cfg, ev, motion, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 5000:
             break
+    cpu = host_cpu_info()
     return {"value": ev.shape[0] * reps / el, "unit": "events/s", "cores": 1, "kind": "port",
             "sample": f"{reps} full evaluations (value+gradient) of the same {ev.shape[0]}-event workload, "
                       f"oracle/cmax_oracle.c fp64 scalar C, {el:.1f} s",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cpu_model": cpu["model"], "host": cpu}
 
 
-def cpu_baseline_torch(cfg, ev, motion, budget_s=8.0):
-    """The reference's own kind of CPU code (tensor ops + torch.autograd, oracle/torch_cpu.py) on this host's cores."""
+def _cpu_torch_worker(workload: str, threads: int, budget_s: float):
+    """Child process of cpu_baseline_torch: a FRESH interpreter (its own OpenMP pool, sized by OMP_NUM_THREADS before torch is
+    imported) on every CPU the launcher allowed -- not the GPU process, which is pinned to one NUMA node and whose thread
+    pool was sized before the pinning (round 2's driver line: 128 threads squeezed after the fact, 7 s per evaluation)."""
     import torch
 
     from oracle import torch_cpu
 
+    torch.set_num_threads(threads)
+    cfg = WORKLOADS[workload]
+    ev, motion, _ = make_inputs(cfg, 0, 1)
+    size = (cfg["H"], cfg["W"])
+    torch_cpu.value_and_grad(ev, motion, cfg["model"], size, cfg["cost"])  # warm-up: thread pool, allocator
+    times = []
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        torch_cpu.value_and_grad(ev, motion, cfg["model"], size, cfg["cost"])
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s or len(times) >= 200:
+            break
+    print(json.dumps({"n": int(ev.shape[0]), "reps": len(times), "total_s": float(sum(times)), "median_s": float(np.median(times)),
+                      "threads": torch.get_num_threads(), "affinity": len(os.sched_getaffinity(0))}), flush=True)
+
+
+def cpu_baseline_torch(workload, cfg, affinity, budget_s=4.0):
+    """The reference's own kind of CPU code (tensor ops + torch.autograd, oracle/torch_cpu.py) on this host's cores: one row
+    with one thread per physical core the launcher allowed, one row with ONE thread, two in between.  Each row
+    runs in its own fresh interpreter (see _cpu_torch_worker).  `affinity`: the CPU set this process had BEFORE it pinned itself."""
     if cfg["sigma"] > 0 or cfg["model"] not in ("2d-translation", "dense-flow") or cfg["cost"] not in ("image_variance", "gradient_magnitude"):
         return None
-    size = (cfg["H"], cfg["W"])
-    torch_cpu.value_and_grad(ev[:1000], motion, cfg["model"], size, cfg["cost"])
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        torch_cpu.value_and_grad(ev, motion, cfg["model"], size, cfg["cost"])
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 200:
-            break
-    return {"value": ev.shape[0] * reps / el, "unit": "events/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} full evaluations (value + autograd gradient) of the same {ev.shape[0]}-event workload, torch-CPU fp64 "
-                      f"restatement of the reference's tensor path (oracle/torch_cpu.py), {el:.1f} s",
-            "host_cpus": os.cpu_count()}
+    cpu = host_cpu_info()
+    n_aff = len(affinity)
+    smt = max(1, (cpu["logical_cpus"] or n_aff) // (cpu["physical_cores"] or n_aff))
+    n_threads = max(1, n_aff // smt)  # one thread per physical core: SMT siblings only contend for these memory-bound ops
+    # the scatter-add / gather ops of this path do not scale with threads (on the 2-socket GPU hosts one thread beats 128), so a
+    # small sweep is reported and the BEST row is the headline of this object
+    sweep = sorted({1, min(8, n_threads), min(32, n_threads), n_threads})
+    rows = {}
+    for threads in sweep:
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-torch-worker", workload, str(threads), str(budget_s)]
+        try:
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s * 6 + 120,
+                                 preexec_fn=lambda: os.sched_setaffinity(0, affinity))
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:  # never fail the bench line over a baseline
+            rows[str(threads)] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            continue
+        rows[str(threads)] = {"value": r["n"] / r["median_s"], "unit": "events/s", "cores": r["threads"], "kind": "port",
+                              "sample": f"{r['reps']} full evaluations (value + autograd gradient) of the same {r['n']}-event workload, torch-CPU "
+                                        f"fp64 restatement of the reference's tensor path (oracle/torch_cpu.py), median of the evaluations, "
+                                        f"{r['total_s']:.1f} s, fresh process on {r['affinity']} CPUs"}
+    ok = {k: v for k, v in rows.items() if "value" in v}
+    if not ok:
+        return {"error": next(iter(rows.values())).get("error", "no result"), "host": cpu}
+    best = max(ok, key=lambda k: ok[k]["value"])
+    out = dict(ok[best])
+    out["threads_sweep"] = {k: (v.get("value") or v.get("error")) for k, v in rows.items()}
+    out["one_thread"] = rows.get("1")
+    out["all_cores"] = rows.get(str(n_threads))
+    out["host_cpus"] = os.cpu_count()
+    out["cpu_model"] = cpu["model"]
+    out["host"] = cpu
+    return out
 
 
 def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=True, keep_inputs=False):
@@ -172,7 +274,7 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     if args.deterministic:
         handle.set_deterministic(True)
     sliced = TimeSlicedObjective(handle, in_library=not args.torch_collectives)
-    ev_dev = torch.from_numpy(ev).to(dev)  # fp64 [n,4] resident in HBM before anything is timed
+    ev_dev = ev.to(dev) if isinstance(ev, torch.Tensor) else torch.from_numpy(ev).to(dev)  # fp64 [n,4] resident in HBM before anything is timed
     sliced.set_local_events(ev_dev, time_bin=T, device=dev)  # first call: workspace allocation, code-object load
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -383,6 +485,9 @@ def self_launch(args):
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-torch-worker":
+        _cpu_torch_worker(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -426,6 +531,7 @@ def main():
             dist.init_process_group(backend="gloo")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    launch_affinity = set(os.sched_getaffinity(0))  # what the launcher allowed (the CPU baselines run on all of it)
     host_affinity = None if args.no_pin else pin_to_gpu_numa_node(dev.index)
 
     main_res = run_workload(args.workload, args, rank, world, dev, args.steps, args.warmup, args.windows, keep_inputs=True)
@@ -434,7 +540,10 @@ def main():
     also = {}
     if not args.no_also:
         # the other configurations, fewer steps (their evaluations are 2-10x longer); same timing protocol
-        names = [w for w in ("cfg3", "cfg4", "cfg5") if w != args.workload] if world == 1 else ["cfg5_strong"]
+        # N = 1: the other single-GPU configurations, cfg5 as BASELINE states it on ONE GPU (the N = 1 point of its strong-scaling
+        # curve), a working set larger than the Infinity Cache, and the headline's second rows (blur; sharp image)
+        names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_sigma1", "cfg2_structured") if w != args.workload]
+                 if world == 1 else ["cfg5_strong"])
         for wname in names:
             r = run_workload(wname, args, rank, world, dev, max(10, args.steps // 4), max(3, args.warmup // 4), max(5, args.windows // 2))
             dom = r.get("dominant")
@@ -442,6 +551,8 @@ def main():
                            "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "events/s",
                            "scaling": "strong" if WORKLOADS[wname].get("strong") else "weak",
                            "evaluation_frac": r["evaluation_frac"], "evaluation_GBps_per_gpu": r["evaluation_GBps_per_gpu"],
+                           "evaluation_bytes_per_gpu": r["evaluation_bytes_per_gpu"], "packed_event_stream_bytes": 8 * r["events_per_gpu"],
+                           "window_ms_per_step": r["window_ms_per_step"], "loss": r["loss"],
                            "dominant_kernel": r["kernels"][dom]["kernel"] if dom else None,
                            "dominant_kernel_us": r["kernels"][dom]["launch_us"] if dom else None,
                            "dominant_kernel_frac": r["kernels"][dom]["frac"] if dom else None,
@@ -479,6 +590,7 @@ def main():
                          "frac": main_res["evaluation_frac"],
                          "algorithmic_bytes_per_evaluation": main_res["evaluation_bytes_per_gpu"],
                          "traffic": sum(v for v in (measured_traffic(args.workload, k) for k in ("vote", "stats", "gimage", "grad", "finish")) if v) or None,
+                         "traffic_source": traffic_source(args.workload),
                          "dominant": {"kernel": kd["kernel"], "achieved": kd["GBps"], "frac": kd["frac"], "launch_us": kd["launch_us"],
                                       "algorithmic_bytes_per_launch": kd["algorithmic_bytes_per_launch"], "traffic": kd["traffic"]},
                          "kernels": main_res["kernels"], "method": main_res["profile_method"]},
@@ -491,7 +603,7 @@ def main():
             out["graph_replay"] = graph_replay_rate(cfg, ev, motion, dev, max(args.steps, 50), min(args.windows, 11))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ev, motion)
-            tc = cpu_baseline_torch(cfg, ev, motion)
+            tc = cpu_baseline_torch(args.workload, cfg, launch_affinity)
             if tc is not None:
                 out["cpu_baseline_torch"] = tc
         print(json.dumps(out), flush=True)

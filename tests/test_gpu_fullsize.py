@@ -149,6 +149,50 @@ def test_cfg5_two_time_slices_of_5m_against_the_oracle():
     assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL
 
 
+def test_cfg5_full_20m_eight_slices():
+    """cfg5 AS BASELINE STATES IT (configs[4]): 20M events on 720x1280, dense flow, variance, time-sliced x 8 -- eight
+    handles on this GPU standing for the eight ranks, each with its contiguous 2.5M-event time slice and the batch-wide
+    extremes; images summed the way C1 does, every rank finishing on the summed image, gradients summed the way C2
+    does -- against the oracle on all 20M events.  Also the N = 1 point of the strong-scaling curve: ONE handle holding
+    the whole batch (bench.py `also.cfg5_strong`), same gate."""
+    size, n, world = (720, 1280), 20_000_000, 8
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
+    desc = E.make_descriptor("image_variance", "dense-flow")
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
+    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    gmax = np.abs(ref["grad"]).max()
+    tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
+    from event_based_optical_flow_amd.distributed import time_slice_bounds
+
+    ranks = []
+    for r in range(world):
+        lo, hi = time_slice_bounds(n, world, r)
+        ranks.append(E.CMaxHandle(size).set_events(torch.from_numpy(ev[lo:hi]).cuda(), tmin, tmax))
+    assert sum(h.n_events for h in ranks) == n
+    images = sum(h.objective_vote(desc, flow) for h in ranks)  # C1
+    outs = [h.objective_finish(desc, flow, images) for h in ranks]
+    gsum = sum(g.double() for _, g in outs).cpu().numpy()  # C2
+    e_iwe = rel_max(images[0].cpu().numpy(), ref["iwes"]["iwe"])
+    e_loss = max(abs(o[0][0].item() - ref["loss"]) / abs(ref["loss"]) for o in outs)
+    err = np.abs(gsum - ref["grad"])
+    e_gate = (err - 1.01 * bound).max() / gmax
+    n_over = int((err > TOL * gmax).sum())
+    print(f"[fullsize] cfg5 20M = 8 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {err.max() / gmax:.2e} | gated {e_gate:.2e} "
+          f"({n_over} of {err.size} gradient entries above 1e-4, {n_amb} cell-border events)")
+    assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL
+    assert n_over <= 2 * n_amb
+    for h in ranks:
+        h.close()
+    del ranks, images, outs
+    # N = 1: the whole batch behind one handle
+    h = E.CMaxHandle(size).set_events(torch.from_numpy(ev).cuda())
+    assert h.n_events == n
+    res, grad = h.evaluate(desc, flow)
+    check("cfg5 20M 720x1280 dense variance, one handle", h, res, grad, ref, bound, n_amb)
+    h.close()
+
+
 @pytest.mark.parametrize("model,sigma,omit", [("dense-flow", 0, True), ("dense-flow", 0, False), ("dense-flow-voxel", 0, True),
                                                ("dense-flow", 1, True), ("dense-flow", 1, False), ("dense-flow-voxel", 1, True)])
 def test_mean_from_votes_along_the_border(model, sigma, omit):
