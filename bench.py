@@ -59,6 +59,12 @@ WORKLOADS = {
                 desc="hbm: 64M synthetic events, 1280x720, dense flow, image_variance (512 MB packed stream: larger than the Infinity Cache)"),
     # SURVEY 8(d) second rows of the headline: the YAMLs' blur, and a sharp image (2500 dots warped with their true motion --
     # what an optimiser converges to; the friendliest case for LDS / L2 atomics is the uniform stream above)
+    # the headline's other two forms (see run_workload): results left ON THE DEVICE by a finishing kernel (cmax_objective), and
+    # results delivered TO THE HOST after every evaluation (cmax_objective_host: what a sequential optimiser sees)
+    "cfg2_device_result": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="device",
+                               desc="cfg2 through cmax_objective: loss + gradient finished on the device (K1, K3, k_finish_raw)"),
+    "cfg2_host_result": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="host",
+                             desc="cfg2 through cmax_objective_host: every evaluation returns loss + gradient to the host before the next starts"),
     "cfg2_sigma1": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=1.0,
                         desc="cfg2 with the YAMLs' blur: 1M uniform events, 346x260, 2-DoF, image_variance, sigma 1"),
     "cfg2_structured": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, structured=True,
@@ -294,7 +300,21 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     # one evaluation = one prepared library call (outputs allocated once, pointers resolved once: what a solver loop in C
     # would do; `evaluate` spends ~6 us per call in Python, which on a busy host is the difference between a GPU-bound and a
     # host-bound 17 us evaluation -- profiles/r02_ablation.txt)
-    call, res, grad = sliced.prepare(desc, motion_dev, want_grad=True)
+    # Form of the evaluation.  "raw" (default where the objective has one: 2-DoF image variance on one GPU): K1 + K3 leave 32 x 6
+    # partial sums on the device and the CONSUMER folds them on the host when it reads the result (cmax_objective_raw +
+    # cmax_finalize_raw_host; here: once per run, for `loss`, as the device-result form is read once per run) -- no finishing
+    # launch.  "device": cmax_objective, loss and gradient finished on the device.  "host": cmax_objective_host, every step waits
+    # for its numbers on the host (sequential, latency-bound: what one optimiser iteration costs).
+    form = cfg.get("form") or args.form
+    finalize = None
+    if form in ("auto", "raw") and world == 1 and handle.has_raw(desc):
+        call, res, finalize = handle.prepare_raw(desc, motion_dev)
+        grad, form = None, "raw"
+    elif form == "host" and world == 1:
+        call, res, grad = handle.prepare_host(desc, motion_dev)
+    else:
+        call, res, grad = sliced.prepare(desc, motion_dev, want_grad=True)
+        form = "device"
 
     def step():
         call()
@@ -330,7 +350,7 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
         dist.all_reduce(times, op=dist.ReduceOp.MAX)  # a window lasts as long as its slowest rank
     times = np.sort(times.cpu().numpy())
     elapsed = float(np.median(times))
-    loss = float(res[0].item())
+    loss = float(finalize()[0][0]) if finalize else float(res[0].item() if hasattr(res[0], "item") else res[0])
     n_total = n_local * world
 
     out = {"workload": cfg["desc"], "events_per_gpu": n_local, "events_total": n_total, "image": [H, W], "motion_model": cfg["model"],
@@ -338,7 +358,10 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
            "ms_per_step": elapsed / steps * 1e3, "value": n_total * steps / elapsed,
            "window_ms_per_step": {"min": float(times[0]) / steps * 1e3, "median": elapsed / steps * 1e3, "max": float(times[-1]) / steps * 1e3,
                                   "windows": windows, "steps_per_window": steps},
-           "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives, "deterministic": bool(args.deterministic)}
+           "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives, "deterministic": bool(args.deterministic),
+           "result_form": {"raw": "raw sums on the device, folded by the consumer on the host (cmax_objective_raw + cmax_finalize_raw_host)",
+                           "device": "loss + gradient on the device (cmax_objective)",
+                           "host": "loss + gradient on the host after every evaluation (cmax_objective_host)"}[form]}
     if world > 1:
         out["rccl"] = dict(zip(("nranks", "rank", "version"), handle.comm_info()))
     # B / t_eval.  Per GPU: N/g events + the full images (every rank evaluates the image-space part)
@@ -409,7 +432,11 @@ def graph_replay_rate(cfg, ev, motion, dev, steps, windows):
         handle.set_events(torch.from_numpy(ev).to(dev))
         desc = E.make_descriptor(cfg["cost"], cfg["model"], sigma=cfg["sigma"])
         m = torch.from_numpy(np.asarray(motion)).to(dev).float().contiguous()
-        call, res, grad = handle.prepare(desc, m)
+        finalize = None
+        if handle.has_raw(desc):  # the headline's own form: K1 + K3, raw sums
+            call, res, finalize = handle.prepare_raw(desc, m)
+        else:
+            call, res, grad = handle.prepare(desc, m)
         k = steps + (steps & 1)  # even: the handle's double-buffered images end a replay where they began it
         for _ in range(50):
             call()
@@ -429,7 +456,8 @@ def graph_replay_rate(cfg, ev, motion, dev, steps, windows):
             times.append((time.perf_counter() - t0) / k)
         t = float(np.median(times))
         out = {"ms_per_step": t * 1e3, "value": cfg["n"] / t, "evaluations_per_graph": k, "windows": windows,
-               "loss": float(res[0].item()), "note": "hipGraph replay of the same launches; not the way a solver can call the path"}
+               "loss": float(finalize()[0][0]) if finalize else float(res[0].item()),
+               "note": "hipGraph replay of the same launches; not the way a solver can call the path"}
         handle.close()
         return out
     except Exception as e:  # capture not available / refused: report, never fail the bench line
@@ -505,6 +533,9 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: all-reduce with torch.distributed around the phase-split calls instead of inside the library")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (1-GPU box testing with --backend gloo)")
+    ap.add_argument("--form", default="auto", choices=["auto", "raw", "device", "host"],
+                    help="how an evaluation hands over its result: auto = raw sums where the objective has that form (2-DoF image variance), "
+                         "else device; device = cmax_objective; host = cmax_objective_host (every step waits for its numbers)")
     ap.add_argument("--deterministic", action="store_true", help="cmax_set_deterministic(1): integer accumulation, bit-repeatable results (slower)")
     args = ap.parse_args()
 
@@ -542,7 +573,8 @@ def main():
         # the other configurations, fewer steps (their evaluations are 2-10x longer); same timing protocol
         # N = 1: the other single-GPU configurations, cfg5 as BASELINE states it on ONE GPU (the N = 1 point of its strong-scaling
         # curve), a working set larger than the Infinity Cache, and the headline's second rows (blur; sharp image)
-        names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_sigma1", "cfg2_structured") if w != args.workload]
+        names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_device_result", "cfg2_host_result", "cfg2_sigma1", "cfg2_structured")
+                  if w != args.workload]
                  if world == 1 else ["cfg5_strong"])
         for wname in names:
             r = run_workload(wname, args, rank, world, dev, max(10, args.steps // 4), max(3, args.warmup // 4), max(5, args.windows // 2))
@@ -552,7 +584,7 @@ def main():
                            "scaling": "strong" if WORKLOADS[wname].get("strong") else "weak",
                            "evaluation_frac": r["evaluation_frac"], "evaluation_GBps_per_gpu": r["evaluation_GBps_per_gpu"],
                            "evaluation_bytes_per_gpu": r["evaluation_bytes_per_gpu"], "packed_event_stream_bytes": 8 * r["events_per_gpu"],
-                           "window_ms_per_step": r["window_ms_per_step"], "loss": r["loss"],
+                           "window_ms_per_step": r["window_ms_per_step"], "loss": r["loss"], "result_form": r["result_form"],
                            "dominant_kernel": r["kernels"][dom]["kernel"] if dom else None,
                            "dominant_kernel_us": r["kernels"][dom]["launch_us"] if dom else None,
                            "dominant_kernel_frac": r["kernels"][dom]["frac"] if dom else None,
@@ -578,6 +610,7 @@ def main():
             "data": "synthetic (%s events, seed 46)" % args.events,
             "config": {"workload": cfg["desc"], "events_per_gpu": n, "image": [H, W], "motion_model": cfg["model"],
                        "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "parallelism": f"time-slice x{world}", "deterministic": bool(args.deterministic),
+                       "result_form": main_res["result_form"],
                        "collectives": None if world == 1 else main_res["collectives"] + ": all-reduce(IWE) + all-reduce(grad) per evaluation",
                        "rccl": main_res.get("rccl")},
             "timing": dict(main_res["window_ms_per_step"], ramp_s=args.ramp, host_affinity=host_affinity,

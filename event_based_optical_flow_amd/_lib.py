@@ -40,7 +40,7 @@ class CmaxObjective(ctypes.Structure):
         ("mult", ctypes.c_double * 4),
         ("sigma", ctypes.c_double),
         ("T", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("motion_dtype", ctypes.c_int32),
     ]
 
 
@@ -75,8 +75,10 @@ MODEL_2DOF, MODEL_DENSE, MODEL_VOXEL = 0, 1, 2
 REF_FIRST, REF_LAST, REF_FRAC = 0, 1, 2
 COST_VARIANCE, COST_GRADMAG = 0, 1
 SCHEME_BURGERS, SCHEME_UPWIND = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
+RAW_LINES = 32
+RAW_DOUBLES = RAW_LINES * 16
 PROF_CLASSES = 6
 ECOMM = -5
 
@@ -108,6 +110,10 @@ SIGNATURES = {
     "cmax_set_time_bins": (c_int, [c_vp, c_int, c_vp]),
     "cmax_iwe": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_vp, c_vp]),
     "cmax_objective": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
+    "cmax_objective_host": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
+    "cmax_objective_has_raw": (c_int, [c_vp, ctypes.POINTER(CmaxObjective)]),
+    "cmax_objective_raw": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp]),
+    "cmax_finalize_raw_host": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp]),
     "cmax_objective_hvp": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_vote": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),

@@ -142,6 +142,19 @@ class CMaxHandle:
     def _motion32(self, motion) -> torch.Tensor:
         return to_device_tensor(motion, "motion").detach().to(torch.float32).contiguous()
 
+    def _motion_arg(self, desc: CmaxObjective, motion):
+        """(device tensor, descriptor) for one objective call.  A 2-DoF theta that arrives in fp64 -- the dtype the
+        reference's solver optimises in (src/solver/patch_contrast_pyramid.py:186) -- is handed over as it is
+        (cmax_objective_t::motion_dtype = CMAX_F64): the kernels round it to fp32 for the bulk arithmetic and keep the
+        doubles for the events that lie on a cell border.  Everything else is fp32 on the device."""
+        m = to_device_tensor(motion, "motion").detach()
+        want = _lib.F64 if (desc.model == _lib.MODEL_2DOF and m.dtype == torch.float64) else _lib.F32
+        m = m.contiguous() if want == _lib.F64 else m.to(torch.float32).contiguous()
+        if desc.motion_dtype != want:
+            desc = CmaxObjective.from_buffer_copy(desc)
+            desc.motion_dtype = want
+        return m, desc
+
     def iwe(self, motion, motion_model: Optional[str], direction: Union[str, float] = "first",
             normalize_t: bool = True, sigma: float = 0.0) -> torch.Tensor:
         """Image of warped events, fp32 [Hp, Wp].  motion_model None -> un-warped image (orig_iwe)."""
@@ -160,7 +173,7 @@ class CMaxHandle:
     def evaluate(self, desc: CmaxObjective, motion, want_grad: bool = True):
         """One cmax_objective call.  Returns (result double[8] on device, grad or None).
         result[0] = loss, result[1..n_ref] = raw contrasts, result[5] = contrast of orig_iwe."""
-        m = self._motion32(motion)
+        m, desc = self._motion_arg(desc, motion)
         result = torch.empty(8, dtype=torch.float64, device=self.device)
         grad = None
         if want_grad:
@@ -176,9 +189,11 @@ class CMaxHandle:
         """A prepared cmax_objective (dist: cmax_objective_dist) call for an inner loop that evaluates the SAME motion
         buffer again and again (an optimiser updating it in place, a benchmark): outputs allocated once, pointers
         resolved once.  Returns (call, result, grad); `call()` enqueues one evaluation on the current stream and
-        overwrites result / grad.  `evaluate` spends ~6 us per call in Python (two allocations, tensor checks) -- as
+        overwrites result / grad.  The call reads `call.motion`: that IS `motion` when it is already a contiguous device
+        tensor of the dtype the kernels take (fp32; fp64 for a 2-DoF theta) -- otherwise it is a private converted copy, and an
+        optimiser that updates its own tensor in place must write into `call.motion` instead (call.motion_is_callers tells).  `evaluate` spends ~6 us per call in Python (two allocations, tensor checks) -- as
         much as the three launches of a 1M-event 2-DoF evaluation leave the host to spare (profiles/r02_ablation.txt)."""
-        m = self._motion32(motion)
+        m, desc = self._motion_arg(desc, motion)
         result = torch.empty(8, dtype=torch.float64, device=self.device)
         grad = None
         if want_grad:
@@ -193,13 +208,86 @@ class CMaxHandle:
                 check(rc)
 
         call.keepalive = (m, desc, result, grad)  # the pointers above stay valid as long as the callable lives
+        call.motion = m
+        call.motion_is_callers = isinstance(motion, torch.Tensor) and motion.is_cuda and motion.data_ptr() == m.data_ptr()
         return call, result, grad
+
+    # -- results on the host / raw sums (no finishing kernel) ---------------------------------------------------
+    def evaluate_host(self, desc: CmaxObjective, motion, want_grad: bool = True):
+        """One cmax_objective_host call: the evaluation with its results delivered to the host, the way an optimiser
+        consumes them (the reference's wrapper ends in .cpu().numpy()).  Returns (result float64[8], grad ndarray or None);
+        blocks.  For the 2-DoF image-variance objective no finishing kernel runs: the raw sums ride the copy."""
+        m, desc = self._motion_arg(desc, motion)
+        result = np.empty(8, dtype=np.float64)
+        grad = None
+        if want_grad:
+            grad = np.empty(2, dtype=np.float64) if desc.model == _lib.MODEL_2DOF else np.empty(tuple(m.shape), dtype=np.float32)
+        check(self._lib.cmax_objective_host(self._h, ctypes.byref(desc), m.data_ptr(), result.ctypes.data,
+                                            grad.ctypes.data if grad is not None else None, F._stream()))
+        return result, grad
+
+    def prepare_host(self, desc: CmaxObjective, motion, want_grad: bool = True):
+        """Prepared cmax_objective_host call: (call, result, grad) with `result` / `grad` numpy arrays that every `call()`
+        overwrites (it returns when they are filled)."""
+        m, desc = self._motion_arg(desc, motion)
+        result = np.empty(8, dtype=np.float64)
+        grad = None
+        if want_grad:
+            grad = np.empty(2, dtype=np.float64) if desc.model == _lib.MODEL_2DOF else np.empty(tuple(m.shape), dtype=np.float32)
+        fn = self._lib.cmax_objective_host
+        h, dref, mp, rp, gp, stream = self._h, ctypes.byref(desc), m.data_ptr(), result.ctypes.data, grad.ctypes.data if grad is not None else None, F._stream
+
+        def call():
+            rc = fn(h, dref, mp, rp, gp, stream())
+            if rc:
+                check(rc)
+
+        call.keepalive = (m, desc, result, grad)
+        call.motion = m
+        return call, result, grad
+
+    def has_raw(self, desc: CmaxObjective) -> bool:
+        """Whether `desc` on the current batch has a raw form (cmax_objective_has_raw): 2-DoF, image variance, sigma 0, not
+        normalised, default (non-deterministic) mode, a non-empty batch."""
+        return bool(self._lib.cmax_objective_has_raw(self._h, ctypes.byref(desc)))
+
+    def prepare_raw(self, desc: CmaxObjective, motion):
+        """Prepared cmax_objective_raw call: (call, raw, finalize).  `call()` enqueues K1 + K3 of one evaluation, which leave
+        their partial sums in `raw` (device float64 [n_ref, RAW_DOUBLES]); `finalize()` copies `raw` to the host and returns
+        (result float64[8], grad float64[2]) = cmax_finalize_raw_host -- the consumer's share of the evaluation, a few
+        hundred additions."""
+        m, desc = self._motion_arg(desc, motion)
+        if not self.has_raw(desc):
+            raise _lib.CmaxError(-1, "this objective has no raw form (2-DoF, image variance, sigma 0, not normalised)")
+        raw = torch.empty((desc.n_ref, _lib.RAW_DOUBLES), dtype=torch.float64, device=self.device)
+        host = torch.empty((desc.n_ref, _lib.RAW_DOUBLES), dtype=torch.float64).pin_memory()
+        fn, fin = self._lib.cmax_objective_raw, self._lib.cmax_finalize_raw_host
+        h, dref, mp, rp, stream = self._h, ctypes.byref(desc), m.data_ptr(), raw.data_ptr(), F._stream
+
+        def call():
+            rc = fn(h, dref, mp, rp, stream())
+            if rc:
+                check(rc)
+
+        def finalize():
+            host.copy_(raw, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            result, grad = np.empty(8, dtype=np.float64), np.empty(2, dtype=np.float64)
+            check(fin(h, dref, host.data_ptr(), result.ctypes.data, grad.ctypes.data))
+            return result, grad
+
+        call.keepalive = (m, desc, raw, host)
+        call.motion = m
+        return call, raw, finalize
 
     def hvp(self, desc: CmaxObjective, motion, tangent) -> torch.Tensor:
         """Exact Hessian-vector product H @ tangent of the objective w.r.t. the motion (cmax_objective_hvp):
         what torch.autograd.functional.vhp gives the reference's Newton-CG.  Returns fp64 [2] (2-DoF) or
         fp32 with the motion's shape."""
         m = self._motion32(motion)
+        if desc.motion_dtype != _lib.F32:
+            desc = CmaxObjective.from_buffer_copy(desc)
+            desc.motion_dtype = _lib.F32
         u = to_device_tensor(tangent, "tangent").detach().to(torch.float64)
         umax = u.abs().max()
         if float(umax) == 0.0:
@@ -216,7 +304,7 @@ class CMaxHandle:
     def objective_vote(self, desc: CmaxObjective, motion) -> torch.Tensor:
         """Raw votes of this handle's events: fp32 [n_images, Hp, Wp] (n_ref images, plus the un-warped
         image when a normalised cost needs it).  To be all-reduced (sum) across time slices."""
-        m = self._motion32(motion)
+        m, desc = self._motion_arg(desc, motion)
         images = torch.empty((5,) + self.padded_size, dtype=torch.float32, device=self.device)
         n_images = ctypes.c_int(0)
         check(self._lib.cmax_objective_vote(self._h, ctypes.byref(desc), m.data_ptr(), images.data_ptr(),
@@ -225,7 +313,7 @@ class CMaxHandle:
 
     def objective_finish(self, desc: CmaxObjective, motion, images: torch.Tensor, want_grad: bool = True):
         """Loss from the (globally reduced) images, gradient contribution of this handle's events."""
-        m = self._motion32(motion)
+        m, desc = self._motion_arg(desc, motion)
         images = images.contiguous()
         result = torch.empty(8, dtype=torch.float64, device=self.device)
         grad = None
@@ -303,7 +391,7 @@ class CMaxHandle:
     def evaluate_dist(self, desc: CmaxObjective, motion, want_grad: bool = True):
         """One cmax_objective_dist call: the evaluation of the whole time-sliced batch, both all-reduces enqueued
         by the library between its kernels.  Same returns as `evaluate`, the same on every rank."""
-        m = self._motion32(motion)
+        m, desc = self._motion_arg(desc, motion)
         result = torch.empty(8, dtype=torch.float64, device=self.device)
         grad = None
         if want_grad:

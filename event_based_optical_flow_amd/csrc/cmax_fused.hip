@@ -82,6 +82,7 @@ struct WarpParams {
     int ntc;                   // source tiles per tile row
     float d;                   // reference time as a fraction of the batch period
     int normalize;             // normalize_t
+    int motion_f64;            // 2-DoF only: `motion` points to double[2] (cmax_objective_t::motion_dtype == CMAX_F64)
     const double *tmm;         // device (tmin, tmax)
     const float *motion;       // theta[2] | flow[2,H,W] | voxel[T,2,H,W]
 };
@@ -169,7 +170,14 @@ struct cmax_handle_s {
     // evaluation e+1, so the steady state needs no memset node.  zero_mask[b] bit k: image k of buffer b is zero
     int cur_buf = 0;
     unsigned zero_mask[2] = {0u, 0u};
-    double *d_gpart = nullptr;  // [4 reference times][nseg][2 (or 6: deferred statistics)] per-segment 2-DoF partials
+    double *d_gpart = nullptr;  // [4 reference times][nseg][2] per-segment 2-DoF partials
+    double *d_raw = nullptr;    // [4 reference times][kRawStride] raw sums of the deferred 2-DoF K3 (cmax_objective's own copy)
+    // cmax_objective_host: device outputs + pinned staging of one evaluation whose results go straight to the host
+    double *d_host_result = nullptr;  // [8]
+    void *d_host_grad = nullptr;
+    int64_t host_grad_bytes = 0;
+    double *hp_out = nullptr;  // pinned
+    int64_t hp_out_cap = 0;
     int *d_ticket = nullptr;    // arrival counters of the statistics workgroups inside K3 (kFoldStatsInside): zero between launches
     double *d_musum = nullptr;  // [2 buffers][4 reference times][kMuStride] K1's sums for the blurred variance (RefArgs::musum)
     int mu_buf = 0;             // buffer the next evaluation adds into (the other one is being cleared / is clear)
@@ -431,6 +439,32 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
     return w;
 }
 
+// EXACT CELLS (round 3, 2-DoF).  The image is continuous across a cell border, the gradient is not (it takes its differences of
+// dL/dIWE from the event's own cell), and a 2-DoF gradient is ONE sum over all events: the ~70 of a million events whose
+// displacement lies within fp32 rounding of a border moved it by 6e-4 relative against the reference's fp64 value (the
+// reference's own fp32 path: 1.3e-3, tests/golden/cfg2_fp32_reference.npz).  The fp32 displacement of warp_one is off by at most
+// 2^-24 (|theta| + 5 |dx|) (rounding of tau, of tau - d, of the time scale, of theta, of the product, of the + 1e-6); an event
+// whose fraction a or b comes closer than that to 0 or 1 -- phase_warp tests |a - 1/2| > 1/2 - m, two VALU instructions per
+// axis -- is warped again here, with the arithmetic of src/warp.py:506-515 + src/event_image_converter.py:340 in fp64 on the
+// 32-bit normalised time of tau_refined and the caller's fp64 theta.  ~5e-5 of the events.  (Dense / voxel: the flow itself is
+// fp32 on the device, and their gradients are per pixel, not one sum over the batch.)
+template <bool FRAC>
+__device__ __forceinline__ Warped warp_exact_2dof(const EvView &ev, uint2 e, int64_t i, const WarpParams &wp, double thd0, double thd1) {
+    Warped w;
+    const int ix = (int)(e.x & 0xFFFu), iy = (int)((e.x >> 12) & 0xFFFu);
+    const double period = wp.normalize ? 1.0 : wp.tmm[1] - wp.tmm[0];
+    const double dtd = (tau_refined(e) - (double)wp.d) * period;
+    const double ddx = fma(dtd, thd0, FRAC ? (double)ev.rx[i] : 0.0), ddy = fma(dtd, thd1, FRAC ? (double)ev.ry[i] : 0.0);
+    const double fxd = fmin(fmax(floor(ddx + 1e-6), -8192.0), 8192.0), fyd = fmin(fmax(floor(ddy + 1e-6), -8192.0), 8192.0);
+    w.a = (float)(ddx - fxd);
+    w.b = (float)(ddy - fyd);
+    w.row = ix + (int)fxd + wp.ph;
+    w.col = iy + (int)fyd + wp.pw;
+    w.dt = 0.f;
+    w.src = 0;
+    return w;
+}
+
 __device__ __forceinline__ float time_scale(const WarpParams &wp) {
     return wp.normalize ? 1.0f : (float)(wp.tmm[1] - wp.tmm[0]);
 }
@@ -451,6 +485,7 @@ struct Window {
     int r0, c0, h, w;  // top-left corner in the padded image, extent (clipped to the image and to LDS)
     int stride;        // LDS row stride in words: odd (window_stride), so that the rows of a window start in different banks
     bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
+    bool border;       // 2-DoF: the segment holds an event within fp32 rounding of a cell border (K1's verdict, re-used by K3)
 };
 // how K3 obtains dL/dIWE: from a materialised G image; folded G = c2 (IWE - mu) with the statistics K2 left in
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
@@ -576,6 +611,9 @@ constexpr int kStatSub = 32;   // sub-accumulators per slot
 // the 363 workgroups of a 260 x 346 image kernel spent 5 of their 9.8 us queueing on ONE line (profiles/r02_ablation.txt).
 constexpr int kSubStride = 16;  // doubles between sub-accumulators
 constexpr int kStatStride = kStatSub * kSubStride;
+// raw sums of the deferred 2-DoF K3 (S1x, S1y, S2x, S2y, sum I, sum I^2): kRawLines accumulators per reference time, one line each
+constexpr int kRawLines = CMAX_RAW_LINES, kRawStride = CMAX_RAW_DOUBLES;
+static_assert(kRawLines == kStatSub && kRawStride == kStatStride && (kRawLines & (kRawLines - 1)) == 0, "K1 resets either with the same pattern");
 
 struct ObjParams {
     int cost, normalized, minimize, negate, omit, n_ref;
@@ -1417,9 +1455,40 @@ k_finish(const double *__restrict__ gpart, int n_gpart, double *__restrict__ gth
     }
 }
 
-// 2-DoF, plain variance, deferred statistics: K3 left per segment (S1x, S1y, S2x, S2y, sum I, sum I^2) with
+// 2-DoF, plain variance, deferred statistics: K3 left (S1x, S1y, S2x, S2y, sum I, sum I^2) per reference time with
 //   S1 = sum_e dt * bilinear-difference(1_Omega I),  S2 = the same of 1_Omega.  With G = c (I - mu) 1_Omega,
 //   c = 2 coef / (n - 1):  dL/dtheta = sum_k c_k (S1_k - mu_k S2_k);  loss and coef_k from the image sums.
+// One function for the device (k_finish_deferred, k_finish_raw) and the host (cmax_finalize_raw_host).
+__host__ __device__ inline void finalize_deferred(const ObjParams &op, const double (*S)[6], double v_orig, double *result, double *gtheta) {
+    const int i0 = op.omit ? 1 : 0;
+    const double npix = (double)(op.H - 2 * i0) * (double)(op.W - 2 * i0);
+    double loss = 0.0, g0 = 0.0, g1 = 0.0;
+    for (int k = 0; k < op.n_ref; ++k) {
+        const double mu = S[k][4] / npix;
+        const double v = (S[k][5] - S[k][4] * mu) / (npix - 1.0);  // unbiased like torch.var, image_variance.py:55
+        result[1 + k] = v;
+        double coef;
+        if (!op.normalized) {
+            loss += op.mult[k] * (op.minimize ? -v : v);
+            coef = op.mult[k] * (op.minimize ? -1.0 : 1.0);
+        } else {
+            loss += op.mult[k] * (op.minimize ? v_orig / v : v / v_orig);
+            coef = op.mult[k] * (op.minimize ? -v_orig / (v * v) : 1.0 / v_orig);
+        }
+        if (op.negate) coef = -coef;
+        const double c = coef * 2.0 / (npix - 1.0);
+        g0 += c * (S[k][0] - mu * S[k][2]);
+        g1 += c * (S[k][1] - mu * S[k][3]);
+    }
+    result[0] = op.negate ? -loss : loss;
+    result[5] = v_orig;
+    if (gtheta) {
+        gtheta[0] = g0;
+        gtheta[1] = g1;
+    }
+}
+
+// per-block partials [n_ref][nseg][6] -> loss + gradient (the tangent-image path: k_tan_stats_var leaves kTanBlocks partials)
 __global__ void __launch_bounds__(256)
 k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *__restrict__ gpart, int nseg,
                   double *__restrict__ result, double *__restrict__ gtheta) {
@@ -1439,31 +1508,28 @@ k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *_
         }
     }
     if (threadIdx.x != 0) return;
-    const double npix = region_pixels(op.H, op.W, op.omit);
-    const double v_orig = op.normalized ? orig_value(op, stat) : 0.0;
-    double loss = 0.0, g0 = 0.0, g1 = 0.0;
-    for (int k = 0; k < op.n_ref; ++k) {
-        const double *S = s_sum[k];
-        const double mu = S[4] / npix;
-        const double v = (S[5] - S[4] * mu) / (npix - 1.0);  // unbiased like torch.var, image_variance.py:55
-        result[1 + k] = v;
-        double coef;
-        if (!op.normalized) {
-            loss += op.mult[k] * (op.minimize ? -v : v);
-            coef = op.mult[k] * (op.minimize ? -1.0 : 1.0);
-        } else {
-            loss += op.mult[k] * (op.minimize ? v_orig / v : v / v_orig);
-            coef = op.mult[k] * (op.minimize ? -v_orig / (v * v) : 1.0 / v_orig);
-        }
-        if (op.negate) coef = -coef;
-        const double c = coef * 2.0 / (npix - 1.0);
-        g0 += c * (S[0] - mu * S[2]);
-        g1 += c * (S[1] - mu * S[3]);
+    finalize_deferred(op, s_sum, op.normalized ? orig_value(op, stat) : 0.0, result, gtheta);
+}
+
+// The raw sums of the deferred K3 (kRawLines lines of six doubles per reference time) -> loss + gradient: ONE wave, lane l
+// loads line l (all loads of all reference times in flight together), DPP sums, lane 63 finishes.  This launch exists only
+// for callers that want the result ON THE DEVICE (cmax_objective); cmax_objective_raw / cmax_objective_host fold on the host.
+__global__ void __launch_bounds__(64)
+k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__restrict__ raw, double *__restrict__ result, double *__restrict__ gtheta) {
+    const int lane = threadIdx.x;
+    double v[4][6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[k][q] = (k < op.n_ref && lane < kRawLines) ? raw[(int64_t)k * kRawStride + lane * kSubStride + q] : 0.0;
+    const double v_orig = op.normalized ? orig_value<true>(op, stat) : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= op.n_ref) break;  // (uniform: 18 VALU instructions per sum, and there is only this one wave)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[k][q] = wave_sum_lane63(v[k][q]);
     }
-    result[0] = op.negate ? -loss : loss;
-    result[5] = v_orig;
-    gtheta[0] = g0;
-    gtheta[1] = g1;
+    if (lane == kWave - 1) finalize_deferred(op, v, v_orig, result, gtheta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1614,7 +1680,7 @@ static EvView ev_view(const cmax_handle_s *h) {
     return ev;
 }
 
-static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T, int ref_mode, double frac, int normalize) {
+static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T, int ref_mode, double frac, int normalize, int motion_f64 = 0) {
     // wp.d is what the single-reference kernels (tangent / HVP) read; the batched kernels take it from RefArgs
     WarpParams wp;
     wp.H = h->H;
@@ -1627,6 +1693,7 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
     wp.ntc = h->ntc;
     wp.d = ref_fraction(ref_mode, frac);
     wp.normalize = normalize;
+    wp.motion_f64 = motion_f64;
     wp.tmm = h->d_tmm;
     wp.motion = motion;
     return wp;
@@ -1637,7 +1704,7 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
 // mu_taps: non-null = also accumulate sum_p I[p] B[p] for the blurred variance (taps k0, k1 of the blur, omit_boundary in [2])
 static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, int n_ref, const int *ref_mode, const double *ref_frac,
                        int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s, bool publish_windows = false,
-                       const float *mu_taps = nullptr) {
+                       const float *mu_taps = nullptr, int motion_f64 = 0, double *raw_reset = nullptr) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     RefArgs ra = {};
     ra.k0 = 0;
@@ -1655,7 +1722,9 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
     for (int k = 0; k < n_ref; ++k) {
         if (!det && !((zero_mask >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(imgs[k], 0, npix * sizeof(float), s));
         if (det) ra.img64[k] = h->img64 + (int64_t)k * npix;
-        double *stat_zero = stat_slot0 >= 0 ? h->d_stat + (stat_slot0 + k) * kStatStride : nullptr;
+        // accumulators K1's first workgroup resets: the statistics of slot stat_slot0 + k, or (deferred 2-DoF objective: no
+        // statistics kernel runs) the raw sums K3 of the same evaluation adds into
+        double *stat_zero = raw_reset ? raw_reset + (int64_t)k * kRawStride : (stat_slot0 >= 0 ? h->d_stat + (stat_slot0 + k) * kStatStride : nullptr);
         if (h->n == 0 && stat_zero)  // no K1 launch on this rank: reset the accumulators explicitly
             CMAX_CHECK_HIP(hipMemsetAsync(stat_zero, 0, kStatStride * sizeof(double), s));
         ra.d[k] = ref_fraction(ref_mode[k], ref_frac[k]);
@@ -1670,7 +1739,7 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
     }
     if (h->n == 0) return 0;
     const EvView ev = ev_view(h);
-    const WarpParams wp = warp_params(h, motion, T, ref_mode[0], ref_frac[0], normalize);
+    const WarpParams wp = warp_params(h, motion, T, ref_mode[0], ref_frac[0], normalize, motion_f64);
     switch (model) {
         case CMAX_MODEL_2DOF: launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, ra, n_ref, s); break;
         case CMAX_MODEL_DENSE: launch_vote<CMAX_MODEL_DENSE>(h, ev, wp, ra, n_ref, s); break;
@@ -1906,7 +1975,7 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         dev_free(&h->d_win);
         int rc = dev_alloc(h, &h->d_segs, h->nseg);
         if (!rc) rc = dev_alloc(h, &h->d_win, (int64_t)4 * h->nseg);
-        if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 6);
+        if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 2);
         if (rc) return rc;
         h->seg_cap = h->nseg;
     }
@@ -2027,6 +2096,8 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     if (!rc) rc = dev_alloc(h, &h->cursor, h->nkeys);
     if (!rc) rc = dev_alloc(h, &h->scan_tmp, div_up(h->nkeys, kScanChunk) + 1);
     if (!rc) rc = dev_alloc(h, &h->d_flags, 4);
+    if (!rc) rc = dev_alloc(h, &h->d_raw, 4 * kRawStride);
+    if (!rc) rc = dev_alloc(h, &h->d_host_result, 8);
     if (!rc) rc = dev_alloc(h, &h->d_musum, 2 * 4 * kMuStride);
     if (!rc) rc = dev_alloc(h, &h->d_ticket, kTicketLines * kTicketLineInts);
     if (!rc && hipMemset(h->d_ticket, 0, kTicketLines * kTicketLineInts * sizeof(int)) != hipSuccess) {
@@ -2064,6 +2135,10 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->d_tmm);
     dev_free(&h->d_stat);
     dev_free(&h->d_musum);
+    dev_free(&h->d_raw);
+    dev_free(&h->d_host_result);
+    if (h->d_host_grad) (void)hipFree(h->d_host_grad);
+    if (h->hp_out) (void)hipHostFree(h->hp_out);
     dev_free(&h->d_ticket);
     dev_free(&h->hvp_img);
     dev_free(&h->d_stat_tan);
@@ -2193,6 +2268,8 @@ static int check_objective_args(cmax_handle_t h, const cmax_objective_t *d, cons
     CMAX_REQUIRE(d->model >= CMAX_MODEL_2DOF && d->model <= CMAX_MODEL_VOXEL, "objective: model");
     CMAX_REQUIRE(d->cost == CMAX_COST_VARIANCE || d->cost == CMAX_COST_GRADMAG, "objective: cost");
     CMAX_REQUIRE(d->n_ref >= 1 && d->n_ref <= 4, "objective: n_ref");
+    CMAX_REQUIRE(d->motion_dtype == CMAX_F32 || (d->motion_dtype == CMAX_F64 && d->model == CMAX_MODEL_2DOF),
+                 "objective: motion_dtype must be CMAX_F32, or CMAX_F64 for the 2-DoF model");
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || (d->T > 0 && d->T == h->n_time_bin), "objective: voxel T must match the handle's time bins");
     CMAX_REQUIRE(!d->omit_boundary || (h->Hp > 2 && h->Wp > 2), "objective: image too small for omit_boundary");
     CMAX_REQUIRE((int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W * 4 < ((int64_t)1 << 32),
@@ -2215,7 +2292,7 @@ static bool owned_groups_apply(const cmax_handle_s *h, const cmax_objective_t *d
 // votes of every reference time (+ the un-warped image when needed) into images[0 .. n_images);
 // zero_mask bit k: images[k] is already zero (the handle's double-buffered images)
 static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
-                          int *n_images_out, hipStream_t s, bool want_mu = false) {
+                          int *n_images_out, hipStream_t s, bool want_mu = false, double *raw_reset = nullptr) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     h->mu_valid = false;
     {
@@ -2229,7 +2306,7 @@ static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const floa
             mu_taps[1] = (float)k1;
         }
         int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s, true,
-                             want_mu ? mu_taps : nullptr);
+                             want_mu ? mu_taps : nullptr, d->motion_dtype == CMAX_F64, raw_reset);
         if (rc) return rc;
     }
     int n_images = d->n_ref;
@@ -2243,8 +2320,9 @@ static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const floa
     return 0;
 }
 
-int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, int *n_images_host,
+int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, float *images, int *n_images_host,
                         cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(images && n_images_host, "objective_vote: images / n_images_host");
@@ -2255,8 +2333,16 @@ int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float 
 // reuse_windows: the caller guarantees that `motion` still holds the values of the vote that published h->d_win
 // (cmax_objective / cmax_objective_dist: same call).  The stand-alone cmax_objective_finish cannot know -- a caching
 // allocator hands the same address to a different motion -- and lets K3 derive its windows again.
+// raw: the accumulators of the deferred 2-DoF K3 (null: the handle's own); raw_is_reset: K1 of this evaluation cleared them;
+// raw_only: stop there -- the caller folds the sums itself (cmax_objective_raw / cmax_objective_host), no finishing launch
+static bool deferred_applies(const cmax_handle_s *h, const cmax_objective_t *d, const void *grad) {
+    return !h->deterministic && grad && d->model == CMAX_MODEL_2DOF && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) && h->n > 0 &&
+           (int64_t)h->Hp * h->Wp <= (int64_t)h->nseg * 8192;
+}
+
 static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
-                            float *zero_next, double *result, void *grad, hipStream_t s, bool reuse_windows) {
+                            float *zero_next, double *result, void *grad, hipStream_t s, bool reuse_windows, double *raw = nullptr,
+                            bool raw_is_reset = false, bool raw_only = false) {
     int rc = 0;
     const int Hp = h->Hp, Wp = h->Wp;
     const int64_t npix = (int64_t)Hp * Wp;
@@ -2292,7 +2378,13 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // deterministic mode: the unfused image path (k_blur3, k_stats with one workgroup per accumulator, k_gimage, k_blur3_adj:
     // every sum in a fixed order) and the integer-accumulating K3
     const bool det = h->deterministic;
-    const bool deferred = !det && grad && two_dof && fold_var && h->n > 0 && npix <= (int64_t)h->nseg * 8192;
+    const bool deferred = deferred_applies(h, d, grad);
+    if (raw_only && !deferred) {
+        set_error("objective_raw: this objective has no raw form (2-DoF, image variance, sigma 0, a non-empty batch, not deterministic)");
+        return CMAX_EINVAL;
+    }
+    if (deferred && !raw) raw = h->d_raw;
+    if (deferred && !raw_is_reset) CMAX_CHECK_HIP(hipMemsetAsync(raw, 0, (size_t)d->n_ref * kRawStride * sizeof(double), s));
     // gradient magnitude with a gradient: K2 and K2b (and the blurs) are one kernel: statistics + G image without its chain factor
     const bool fused_gm = !det && grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
     const bool blur_var = !det && d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
@@ -2450,10 +2542,10 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         ra.n_events = h->n;
     }
     const EvView ev = ev_view(h);
-    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
+    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
     double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
     switch (d->model) {
-        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, h->d_gpart, nullptr, res, false, s); break;
+        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, deferred ? raw : h->d_gpart, nullptr, res, false, s); break;
         case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
         default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
     }
@@ -2466,9 +2558,11 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             hipLaunchKernelGGL(k_fixed_to_grad, dim3(stream_grid(gcount, 256)), dim3(256), 0, s, h->g64, (float *)grad, gcount, h->d_det_inv_scale);
         CMAX_CHECK_LAUNCH();
     } else if (deferred) {
-        ProfScope prof(h, kProfFinish, s);
-        hipLaunchKernelGGL(k_finish_deferred, dim3(1), dim3(256), 0, s, op, h->d_stat, h->d_gpart, h->nseg, result, (double *)grad);
-        CMAX_CHECK_LAUNCH();
+        if (!raw_only) {
+            ProfScope prof(h, kProfFinish, s);
+            hipLaunchKernelGGL(k_finish_raw, dim3(1), dim3(64), 0, s, op, h->d_stat, raw, result, (double *)grad);
+            CMAX_CHECK_LAUNCH();
+        }
     } else if (two_dof) {
         ProfScope prof(h, kProfFinish, s);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)grad);
@@ -2477,8 +2571,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     return 0;
 }
 
-int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
+int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, const float *images, int n_images,
                           double *result, void *grad, cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(images && result, "objective_finish: images / result");
@@ -2519,7 +2614,7 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
     }
     const unsigned used = (1u << nr) - 1u;
     h->tan_zero_mask[h->tan_cur] &= ~used;
-    const WarpParams wp = warp_params(h, motion, 0, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
+    const WarpParams wp = warp_params(h, motion, 0, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
     if (h->n > 0) {
         const EvView ev = ev_view(h);
         const dim3 grid(8 * ((h->nseg + 7) / 8), nr);
@@ -2555,10 +2650,15 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
 }
 
 // vote -> [all-reduce of the images] -> finish -> [all-reduce of the gradient], all on the handle's double-buffered images
+// raw_out: non-null = stop at the raw sums of the deferred 2-DoF K3 (cmax_objective_raw; `grad` is then only a non-null marker)
 static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s,
-                          cmax::Comm *comm) {
+                          cmax::Comm *comm, double *raw_out = nullptr) {
     const bool dist = comm != nullptr;  // also a 1-rank communicator: the same enqueue sequence, RCCL included
-    if ((h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
+    if (!raw_out && (h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
+    if (raw_out && !deferred_applies(h, d, grad)) {
+        set_error("objective_raw: this objective has no raw form (2-DoF, image variance, sigma 0, a non-empty batch, not deterministic)");
+        return CMAX_EINVAL;
+    }
     const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
     const size_t gbytes = d->model == CMAX_MODEL_2DOF ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
     // empty batch: loss 0, zero gradient (patch_contrast_base.py:253-255).  A time slice may be empty while the batch is not.
@@ -2581,7 +2681,9 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     static const bool no_stats_inside = getenv("CMAX_NO_STATS_INSIDE") != nullptr;  // tuning: k_stats as a launch of its own
     const bool var_from_votes = !dist && !no_stats_inside && owned_groups_apply(h, d, grad) && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) &&
                                 !d->normalized && h->Hp >= 4 && h->Wp >= 4;
-    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes || var_from_votes);
+    // deferred 2-DoF objective: K1 clears the raw sums its K3 adds into
+    double *raw = deferred_applies(h, d, grad) ? (raw_out ? raw_out : h->d_raw) : nullptr;
+    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes || var_from_votes, raw);
     if (rc) return rc;
     const unsigned used = (1u << n_images) - 1u;
     h->zero_mask[h->cur_buf] &= ~used;  // now holds votes
@@ -2590,11 +2692,11 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
         rc = comm_allreduce(comm, cur, (size_t)n_images * npix, kCommF32, kCommSum, s);
         if (rc) return rc;
     }
-    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true);
+    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true, raw, raw != nullptr, raw_out != nullptr);
     if (rc) return rc;
     h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
     h->cur_buf ^= 1;
-    if (dist && grad) {  // C2
+    if (dist && grad && !raw_out) {  // C2
         ProfScope prof(h, kProfComm, s);
         rc = comm_allreduce(comm, grad, (size_t)gcount, d->model == CMAX_MODEL_2DOF ? kCommF64 : kCommF32, kCommSum, s);
         if (rc) return rc;
@@ -2602,20 +2704,107 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     return 0;
 }
 
-int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad,
+int cmax_objective(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, double *result, void *grad,
                    cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(result, "objective: result");
     return objective_eval(h, d, motion, result, grad, (hipStream_t)stream, nullptr);
 }
 
-int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad,
+int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, double *result, void *grad,
                         cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(result, "objective_dist: result");
     return objective_eval(h, d, motion, result, grad, (hipStream_t)stream, h->comm);
+}
+
+int cmax_objective_has_raw(cmax_handle_t h, const cmax_objective_t *d) {
+    if (!h || !d) return 0;
+    return deferred_applies(h, d, (const void *)h) && !d->normalized ? 1 : 0;
+}
+
+int cmax_objective_raw(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, double *raw, cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(raw, "objective_raw: raw");
+    CMAX_REQUIRE(!d->normalized, "objective_raw: normalised costs need the un-warped image's statistics: use cmax_objective");
+    return objective_eval(h, d, motion, nullptr, (void *)raw, (hipStream_t)stream, nullptr, raw);
+}
+
+int cmax_finalize_raw_host(cmax_handle_t h, const cmax_objective_t *d, const double *raw_host, double *result_host, double *grad_host) {
+    CMAX_REQUIRE(h && d && raw_host && result_host, "finalize_raw_host: null pointer");
+    CMAX_REQUIRE(d->n_ref >= 1 && d->n_ref <= 4 && !d->normalized, "finalize_raw_host: descriptor");
+    const ObjParams op = obj_params(h, d);
+    double S[4][6];
+    for (int k = 0; k < d->n_ref; ++k)
+        for (int q = 0; q < 6; ++q) {
+            double a = 0.0;
+            for (int l = 0; l < kRawLines; ++l) a += raw_host[(int64_t)k * kRawStride + l * kSubStride + q];
+            S[k][q] = a;
+        }
+    for (int k = 0; k < 8; ++k) result_host[k] = 0.0;
+    finalize_deferred(op, S, 0.0, result_host, grad_host);
+    return 0;
+}
+
+// busy-wait for the stream: hipStreamSynchronize sleeps in the driver and wakes up ~10 us late (profiles/r02_solver_objective.txt)
+static int spin_until_done(hipStream_t s) {
+    hipError_t e;
+    while ((e = hipStreamQuery(s)) == hipErrorNotReady) {
+    }
+    if (e != hipSuccess) {
+        set_error("stream error while waiting for the evaluation: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, double *result_host, void *grad_host,
+                        cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(result_host, "objective_host: result_host");
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_host && !d->normalized && deferred_applies(h, d, grad_host)) {
+        // K1 -> K3 -> copy of the raw sums; the fold is 6 x 32 additions on the host, behind the copy a host caller makes anyway
+        const size_t bytes = (size_t)d->n_ref * kRawStride * sizeof(double);
+        rc = pinned_reserve(&h->hp_out, &h->hp_out_cap, (int64_t)4 * kRawStride);
+        if (rc) return rc;
+        rc = objective_eval(h, d, motion, nullptr, (void *)h->d_raw, s, nullptr, h->d_raw);
+        if (rc) return rc;
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_out, h->d_raw, bytes, hipMemcpyDeviceToHost, s));
+        rc = spin_until_done(s);
+        if (rc) return rc;
+        return cmax_finalize_raw_host(h, d, h->hp_out, result_host, (double *)grad_host);
+    }
+    const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
+    const int64_t gbytes = grad_host ? (d->model == CMAX_MODEL_2DOF ? 2 * (int64_t)sizeof(double) : gcount * (int64_t)sizeof(float)) : 0;
+    if (gbytes > h->host_grad_bytes) {
+        CMAX_CHECK_HIP(hipStreamSynchronize(s));
+        if (h->d_host_grad) (void)hipFree(h->d_host_grad);
+        h->d_host_grad = nullptr;
+        h->host_grad_bytes = 0;
+        CMAX_CHECK_HIP(hipMalloc(&h->d_host_grad, (size_t)gbytes));
+        h->host_grad_bytes = gbytes;
+        h->bytes += gbytes;
+    }
+    rc = pinned_reserve(&h->hp_out, &h->hp_out_cap, 8 + (gbytes + 7) / 8);
+    if (rc) return rc;
+    rc = objective_eval(h, d, motion, h->d_host_result, grad_host ? h->d_host_grad : nullptr, s, nullptr);
+    if (rc) return rc;
+    CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_out, h->d_host_result, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (grad_host) CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_out + 8, h->d_host_grad, (size_t)gbytes, hipMemcpyDeviceToHost, s));
+    rc = spin_until_done(s);
+    if (rc) return rc;
+    std::memcpy(result_host, h->hp_out, 8 * sizeof(double));
+    if (grad_host) std::memcpy(grad_host, h->hp_out + 8, (size_t)gbytes);
+    return 0;
 }
 
 int cmax_set_deterministic(cmax_handle_t h, int enable) {
@@ -2710,8 +2899,9 @@ static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams
 
 extern "C" {
 
-int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *tangent, void *hv,
+int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, const float *tangent, void *hv,
                        cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(tangent && hv, "objective_hvp: tangent / hv");
@@ -2776,7 +2966,7 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const float *
     }
     tp.fix = tp.fixk[0];
     tp.inv_fix = 1.f / tp.fix;
-    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t);
+    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
     // images, their blur and statistics (slots 0 .. nr-1)
     CMAX_CHECK_HIP(hipMemsetAsync(I, 0, (size_t)nr * npix * sizeof(float), s));
     {

@@ -52,6 +52,26 @@ __device__ __forceinline__ int sort_voxel_bin(double tau, int T) {
     return k;
 }
 
+// The 8 bits above the source pixel of an UN-BINNED handle's packed word hold the residual of the normalised time that fp32
+// cannot: tau = (double)tau32 + q * ulp(tau32) / 256, q in [-128, 127] -- 32 significant bits, enough to decide on which
+// side of a cell border an event lies exactly like the reference's fp64 arithmetic does (see warp_one).  Binned handles keep
+// the voxel time bin there.
+__device__ __forceinline__ uint32_t tau_residual8(double tn) {
+    const float hi = (float)tn;
+    const uint32_t eb = __float_as_uint(hi) & 0x7F800000u;
+    if (eb < (32u << 23)) return 0u;  // |tau| < 2^-95: nothing to refine
+    const double unit = (double)__uint_as_float(eb - (31u << 23));  // ulp(hi) / 256
+    int q = (int)rint((tn - (double)hi) / unit);
+    q = q < -128 ? -128 : (q > 127 ? 127 : q);
+    return (uint32_t)q & 0xFFu;
+}
+__device__ __forceinline__ double tau_refined(uint2 e) {
+    const uint32_t eb = e.y & 0x7F800000u;
+    const int q = (int)e.x >> 24;  // sign-extended
+    const double hi = (double)__uint_as_float(e.y);
+    return eb < (32u << 23) ? hi : hi + (double)q * (double)__uint_as_float(eb - (31u << 23));
+}
+
 // One event as the sort sees it.
 struct SortItem {
     int ix, iy;     // source pixel; ix < 0: not on the sensor (dropped)
@@ -258,7 +278,8 @@ k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__re
         if (tile[u] < 0) continue;
         const SortItem &it = item[u];
         const int pos = lds ? s_base[tile[u]] + atomicAdd(&s_hist[tile[u]], 1) : tile_off[tile[u]] + atomicAdd(&tile_cursor[tile[u]], 1);
-        const uint32_t bin = T > 0 ? (uint32_t)sort_voxel_bin(it.tn, T) : 0u;
+        // top byte: the voxel time bin (binned handle) or the time residual beyond fp32 (un-binned handle, tau_residual8)
+        const uint32_t bin = T > 0 ? (uint32_t)sort_voxel_bin(it.tn, T) : tau_residual8(it.tn);
         out.evp[pos] = make_uint2((uint32_t)it.ix | ((uint32_t)it.iy << 12) | (bin << 24), __float_as_uint((float)it.tn));
         if (frac) {
             out.rx[pos] = it.rx;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CMAX_ABI_VERSION 2
+#define CMAX_ABI_VERSION 3
 
 /* dtypes */
 #define CMAX_F32 0
@@ -223,14 +223,46 @@ typedef struct {
     double mult[4];       /* e.g. forward 1, backward 1, middle 2 */
     double sigma;         /* blur (0 = none) */
     int32_t T;            /* voxel time bins */
-    int32_t reserved;
+    int32_t motion_dtype; /* CMAX_F32 (0): `motion` is fp32.  CMAX_F64: 2-DoF only -- `motion` points to double theta[2], the
+                             optimiser's own fp64 parameters (src/solver/patch_contrast_pyramid.py:186): the bulk arithmetic stays
+                             fp32, but the cell floor(x' + 1e-6) of an event that lies within fp32 rounding of a cell border is
+                             decided in fp64 from this theta, like the reference does (src/event_image_converter.py:340) */
 } cmax_objective_t;
 
 /* One evaluation.  result[0] = loss, result[1..n_ref] = v_k, result[5] = v_orig (device
  * doubles, result has 8 entries).  grad: fp64 [2] for 2DOF, fp32 [2,H,W] / [T,2,H,W] otherwise
- * (overwritten); NULL skips the gradient pass.                                               */
-int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+ * (overwritten); NULL skips the gradient pass.  motion: fp32 theta[2] | flow[2,H,W] | voxel[T,2,H,W]
+ * (or double theta[2], see cmax_objective_t::motion_dtype).                                    */
+int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                    double *result, void *grad, cmax_stream_t stream);
+
+/* The same evaluation with its results delivered TO THE HOST -- what an optimiser written in C calls once per iteration
+ * (the reference's TorchWrapper.get_value_and_grad ends in .cpu().numpy(), src/solver/scipy_autograd/torch_wrapper.py:46-49):
+ * enqueues the evaluation and the copies on `stream` and returns when result_host[8] and grad_host (double[2] for 2DOF, else
+ * fp32 [2,H,W] / [T,2,H,W]; NULL: value only) are filled.  Blocks (busy-waits on the stream).  For the 2-DoF image-variance
+ * objective no finishing kernel runs at all: the gathering kernel leaves CMAX_RAW_LINES x 6 partial sums, which ride the
+ * copy and are folded on the host (see cmax_objective_raw).                                       */
+int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion, double *result_host,
+                        void *grad_host, cmax_stream_t stream);
+
+/* Raw form of the 2-DoF image-variance objective (sigma 0, not normalised, default mode, non-empty batch:
+ * cmax_objective_has_raw says whether a descriptor qualifies).  cmax_objective spends a third of such an evaluation in a
+ * one-workgroup kernel that only adds up what the gathering kernel left and divides a few numbers; here that kernel is not
+ * launched.  `raw` (device, CMAX_RAW_DOUBLES doubles per reference time, cleared by the library inside the evaluation)
+ * receives CMAX_RAW_LINES partial sums -- one 128-byte line each, doubles 0..5 of a line = (S1x, S1y, S2x, S2y, sum I,
+ * sum I^2) with S1 = sum_e dt * bilinear-difference(1_Omega IWE), S2 = the same of 1_Omega -- added with fp64 atomics by the
+ * gathering workgroups.  The CONSUMER finishes: copy the buffer to the host whenever it needs the numbers and call
+ * cmax_finalize_raw_host (pure host arithmetic: sums the lines, then loss = -/+ var, dL/dtheta = c (S1 - mu S2)).
+ * Asynchronous like cmax_objective.                                                              */
+#define CMAX_RAW_LINES 32
+#define CMAX_RAW_DOUBLES (CMAX_RAW_LINES * 16)
+int cmax_objective_has_raw(cmax_handle_t h, const cmax_objective_t *desc_host);
+int cmax_objective_raw(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion, double *raw,
+                       cmax_stream_t stream);
+/* raw_host: host copy of `raw` ([n_ref][CMAX_RAW_DOUBLES]).  result_host[8] as for cmax_objective; grad_host double[2]
+ * (NULL: value only).                                                                            */
+int cmax_finalize_raw_host(cmax_handle_t h, const cmax_objective_t *desc_host, const double *raw_host,
+                           double *result_host, double *grad_host);
 
 /* Exact Hessian-vector product of the objective w.r.t. the motion, H u -- what
  * torch.autograd.functional.vhp returns in the reference (src/solver/scipy_autograd/torch_wrapper.py:
@@ -238,7 +270,7 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const flo
  * bilinear cells held fixed.  tangent: fp32, same layout as motion, SCALED TO UNIT MAX-NORM by the
  * caller (H is linear in u; the derivative votes are accumulated in fixed point).  hv: fp64 [2]
  * (2DOF) or fp32 [2,H,W] / [T,2,H,W], overwritten.  Costs as in cmax_objective.                 */
-int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                        const float *tangent, void *hv, cmax_stream_t stream);
 
 /* Phase-split form for time-sliced multi-GPU runs (one handle per GPU, each holding a contiguous
@@ -253,9 +285,9 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *desc_host, const
  * images: fp32 [5, Hp, Wp] caller-owned.  cmax_objective == vote + finish on internal images.
  * `motion` of the finish call must be the buffer AND the values of the preceding vote call: the gather re-uses
  * the LDS windows the vote derived for every segment.                                          */
-int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                         float *images, int *n_images_host, cmax_stream_t stream);
-int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                           const float *images, int n_images, double *result, void *grad,
                           cmax_stream_t stream);
 
@@ -294,7 +326,7 @@ int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, in
 /* One evaluation of the whole (time-sliced) batch: same arguments and results as cmax_objective,
  * the same on every rank (the gradient bit for bit; the loss up to fp64 summation order when a rank
  * holds no events).  A rank may hold zero events.  Without a communicator: == cmax_objective.   */
-int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const float *motion,
+int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                         double *result, void *grad, cmax_stream_t stream);
 
 /* Deterministic mode ("race detection"): bit-identical IWE, loss and gradient from run

@@ -468,3 +468,89 @@ def test_prepared_call_equals_evaluate_and_follows_the_motion_buffer():
         assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
         assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
         assert abs(res[0].item() - r2[0].item()) <= 1e-6 * abs(r2[0].item()) and rel_max(grad.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: results on the host (cmax_objective_host) and the raw form of the 2-DoF variance objective
+# (cmax_objective_raw + cmax_finalize_raw_host: no finishing kernel, the consumer folds 32 x 6 partial sums)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_ref_cost", ["image_variance", "multi_focal_normalized_image_variance"])
+@pytest.mark.parametrize("pad,frac", [(0, False), (3, True)])
+def test_two_dof_raw_and_host_forms(n_ref_cost, pad, frac):
+    size, n = (120, 160), 200_000
+    ev = E.utils.generate_structured_events(n, size[0], size[1], (9.0, -6.0), n_dots=300, seed=21)
+    if frac:
+        rng = np.random.default_rng(21)
+        ev[:, 0] = np.clip(ev[:, 0] + rng.uniform(0, 0.99, n), 0, size[0] - 1e-3)
+        ev[:, 1] = np.clip(ev[:, 1] + rng.uniform(0, 0.99, n), 0, size[1] - 1e-3)
+    theta = np.array([8.0, -5.0])
+    h = E.CMaxHandle(size, pad).set_events(ev)
+    desc = E.make_descriptor(n_ref_cost, "2d-translation")
+    ref = orc.objective(ev, theta, "2d-translation", size, cost=n_ref_cost, sigma=0, outer_padding=pad)
+    res_d, grad_d = h.evaluate(desc, theta)  # device results (k_finish_raw behind K3)
+    assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"]) and rel_max(grad_d.cpu().numpy(), ref["grad"]) <= TOL
+    for rep in range(3):  # host results, repeated: the raw sums are cleared inside every evaluation
+        res_h, grad_h = h.evaluate_host(desc, theta)
+        assert abs(res_h[0] - ref["loss"]) <= TOL * abs(ref["loss"]), (rep, res_h[0], ref["loss"])
+        assert rel_max(grad_h, ref["grad"]) <= TOL
+    if n_ref_cost == "image_variance":
+        assert h.has_raw(desc)
+        call, raw, finalize = h.prepare_raw(desc, theta)
+        for rep in range(3):
+            call()
+        res_r, grad_r = finalize()
+        assert abs(res_r[0] - ref["loss"]) <= TOL * abs(ref["loss"]) and rel_max(grad_r, ref["grad"]) <= TOL
+        assert abs(res_r[1] - (-ref["loss"])) <= TOL * abs(ref["loss"])  # result[1] = the raw contrast
+        # interleaved with the device-result form on the same handle (they share the vote images, not the sums)
+        call()
+        res_d2, grad_d2 = h.evaluate(desc, theta)
+        res_r2, grad_r2 = finalize()
+        assert abs(res_r2[0] - res_d2[0].item()) <= 1e-6 * abs(res_r2[0]) and rel_max(grad_r2, grad_d2.cpu().numpy()) <= 1e-5
+    else:
+        assert not h.has_raw(desc)  # normalised: needs the un-warped image's statistics on the device
+        with pytest.raises(E._lib.CmaxError):
+            h.prepare_raw(desc, theta)
+
+
+@pytest.mark.parametrize("model,cost,sigma", [("dense-flow", "gradient_magnitude", 1.0), ("dense-flow-voxel", "image_variance", 0.0),
+                                               ("2d-translation", "gradient_magnitude", 0.0)])
+def test_objective_host_other_models(model, cost, sigma):
+    """cmax_objective_host for objectives without a raw form: the same numbers as cmax_objective, on the host."""
+    size, n, Tn = (96, 128), 120_000, 4
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=23)
+    if model == "2d-translation":
+        motion, tb = np.array([7.0, -4.0]), 0
+    elif model == "dense-flow":
+        motion, tb = E.utils.generate_smooth_flow(size, 10, seed=24), 0
+    else:
+        motion, tb = np.stack([E.utils.generate_smooth_flow(size, 10, seed=24 + b) for b in range(Tn)]), Tn
+    h = E.CMaxHandle(size).set_events(ev, time_bin=tb)
+    desc = E.make_descriptor(cost, model, sigma=sigma, time_bin=tb)
+    ref = orc.objective(ev, motion, model, size, cost=cost, sigma=int(sigma))
+    for want_grad in (True, False, True):
+        res, grad = h.evaluate_host(desc, motion, want_grad=want_grad)
+        assert abs(res[0] - ref["loss"]) <= TOL * abs(ref["loss"])
+        if want_grad:
+            assert rel_max(grad, ref["grad"]) <= TOL
+    with pytest.raises(E._lib.CmaxError):
+        h.prepare_raw(desc, motion)
+
+
+def test_exact_cells_fp64_theta_beats_fp32_rounding():
+    """warp_one's exact-cell branch: with theta handed over in fp64 the 2-DoF gradient on UNIFORM events (every one of
+    the 600k a potential cell-border event) meets the plain gate against the fp64 oracle, for all three reference times."""
+    size, n = (260, 346), 600_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=31)
+    theta = np.array([17.123456789, -11.987654321])
+    h = E.CMaxHandle(size).set_events(ev)
+    for direction in ("first", "middle", "last"):
+        desc = E.make_descriptor("image_variance", "2d-translation", warp_direction=direction)
+        res, grad = h.evaluate(desc, theta)
+        warped, _ = orc.warp_event(ev, theta, "2d-translation", direction, size)
+        iwe_ref = orc.create_iwe(warped, size, sigma=0)
+        assert rel_max(h.last_iwe(0).cpu().numpy(), iwe_ref) <= TOL
+        if direction == "first":
+            ref = orc.objective(ev, theta, "2d-translation", size, cost="image_variance", sigma=0)
+            e = rel_max(grad.cpu().numpy(), ref["grad"])
+            print(f"[exact cells] {direction}: gradient rel err {e:.2e}")
+            assert e <= TOL and abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])

@@ -547,6 +547,31 @@ def test_solver_objective_cfg1_size_golden(golden, tag, scale):
 
 
 @pytest.mark.parametrize("tag", ["plain", "burgers"])
+@pytest.mark.parametrize("scale", [1, 4])
+def test_solver_objective_cfg1_variance_golden(golden, tag, scale):
+    """configs[0] read literally (BASELINE: "variance cost"): the shipped YAML with `cost: image_variance` at 260 x 346 /
+    30 000 events -- native plan and autograd path against the reference's objective_scipy + autograd."""
+    g = golden("solver_objective_cfg1_variance")
+    k = f"{tag}_s{scale}"
+    size = tuple(int(v) for v in g["image_size"])
+    ev = g["events"]
+    h = E.CMaxHandle(size).set_events(ev, time_bin=10 if tag == "burgers" else 0)
+    obj = PatchFlowObjective(h, ev[:, 2].max() - ev[:, 2].min(), g[k + "__patch_image_size"], g[k + "__patch_size"],
+                             g[k + "__sliding_window"], g[tag + "__patch_shift"], cost="image_variance", blur_sigma=1,
+                             time_aware=(tag == "burgers"), time_bin=10, flow_interpolation="burgers", t0_flow_location="middle")
+    x = np.asarray(g[k + "__x"], dtype=np.float64)
+    ref_loss, ref_grad = float(g[k + "__loss"]), np.asarray(g[k + "__grad"]).reshape(-1)
+    w = TorchWrapper(obj, precision="float64", device="cuda")
+    w.get_input(x)
+    for path in (("native", "autograd") if obj.has_native_plan else ("autograd",)):
+        w.force_autograd = path == "autograd"
+        loss, grad = w.get_value_and_grad(x)
+        e_loss, e_grad = abs(float(loss) - ref_loss) / abs(ref_loss), rel_max(grad, ref_grad)
+        print(f"[cfg1 variance] {k} {path}: rel err loss {e_loss:.2e} grad {e_grad:.2e}")
+        assert e_loss <= TOL and e_grad <= TOL, (k, path, e_loss, e_grad)
+
+
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
 def test_pinned_optimizer_result(golden, tag):
     """The reference's run_scipy at the coarsest scale (src/solver/patch_contrast_pyramid.py:252-318: Newton-CG, gtol 1e-5,
     maxiter 25, float64) from the SAME start: our objective under scipy must end at the same minimum -- final loss within

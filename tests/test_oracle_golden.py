@@ -301,3 +301,44 @@ def test_pinned_optimizer_result_is_a_minimum_of_the_oracle(golden, tag):
     np.testing.assert_allclose(l0, g[tag + "__loss0"], rtol=1e-10)
     np.testing.assert_allclose(l1, g[tag + "__loss"], rtol=1e-10)
     assert l1 < l0 and np.abs(g1).max() < 0.1 * np.abs(g0).max()
+
+
+# ---- round 3 fixtures: configs[0] with `cost: image_variance`, and the reference's own fp32 / fp64 rows on the bench stream ---
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
+@pytest.mark.parametrize("scale", [1, 4])
+def test_solver_objective_cfg1_variance(golden, tag, scale):
+    """BASELINE configs[0] read literally ("variance cost"): the shipped YAML with `cost: image_variance`, 260 x 346,
+    30 000 events, 2 x 2 and 16 x 16 patches."""
+    g = golden("solver_objective_cfg1_variance")
+    k = f"{tag}_s{scale}"
+    size = tuple(int(v) for v in g["image_size"])
+    loss, grad = orc.solver_objective(g["events"], g[k + "__x"], size, g[k + "__patch_image_size"], g[k + "__patch_size"],
+                                      g[k + "__sliding_window"], g[tag + "__patch_shift"], cost="image_variance", sigma=1,
+                                      time_aware=(tag == "burgers"))
+    np.testing.assert_allclose(loss, g[k + "__loss"], rtol=1e-10)
+    ref = g[k + "__grad"]
+    np.testing.assert_allclose(grad, ref, rtol=1e-7, atol=1e-10 * np.abs(ref).max())
+
+
+def bench_cfg2_stream(g):
+    """The headline stream of bench.py, regenerated from its seed and checked against the fixture's checksums."""
+    import event_based_optical_flow_amd as E
+
+    size, n = tuple(int(v) for v in g["image_size"]), int(g["n"])
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+    np.testing.assert_allclose([ev[:, 0].sum(), ev[:, 1].sum(), ev[:, 2].sum()], g["events_checksum"], rtol=1e-14)
+    return size, ev
+
+
+def test_oracle_on_the_bench_stream_equals_the_reference_fp64_row(golden):
+    """cfg2 AT ITS SIZE: the oracle on bench.py's own 1M-event stream against what the reference's torch path returns for
+    it in fp64 (tests/golden/gen_golden.py cfg2_fp32) -- the value every full-size GPU test is compared with is the
+    reference's, not only the oracle's.  The fixture's fp32 row documents the reference's own fp32 error on this stream."""
+    g = golden("cfg2_fp32_reference")
+    size, ev = bench_cfg2_stream(g)
+    ref = orc.objective(ev, g["theta"], "2d-translation", size, cost="image_variance", sigma=0)
+    assert abs(ref["loss"] - float(g["f64__loss"])) <= 1e-11 * abs(float(g["f64__loss"]))
+    np.testing.assert_allclose(ref["grad"], g["f64__grad"], rtol=0, atol=1e-9 * np.abs(g["f64__grad"]).max())
+    assert abs(ref["iwes"]["iwe"].sum() - float(g["f64__iwe_sum"])) <= 1e-9 * float(g["f64__iwe_sum"])
+    # what the reference's fp32 evaluation makes of the same stream: outside the 1e-4 gate
+    assert float(g["fp32_grad_rel_err"]) > 1e-4 and int(g["events_in_another_cell_in_fp32"]) > 0
