@@ -512,6 +512,12 @@ constexpr int kScratch = 200;       // scratch words behind the window; the fast
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
 static_assert(kScratch >= 64 + kWinMaxW + 2, "scratch must hold a per-lane 2x2 footprint at the widest stride");
 
+// Compiler barrier on a loaded value.  `x = cond ? p[i] : 0` -- and even an unconditional load whose only use is such a
+// select -- is compiled into an exec-masked block that holds the load AND its s_waitcnt: a thread that wants four loads in flight
+// gets four dependent round trips to memory (found in round 3 in the ISA of K1 / K3 / k_stats: profiles/r03_ablation.txt).  Load
+// unconditionally (clamped index), pin() every value, select afterwards: the loads are then issued back to back.
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+
 // 16 bytes of zeros, written through the L2 (sc1): see the deferred-statistics K3
 typedef float float4_v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_zero4_sc1(float *p) {
@@ -771,9 +777,13 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
             const unsigned r = p / (unsigned)W, c = p - r * (unsigned)W;
             in[u] = p < npix && (int)r >= i0 && (int)r < H - i0 && (int)c >= i0 && (int)c < W - i0;
             x[u] = 0.f;
-            if (COST == CMAX_COST_VARIANCE) {
-                if (in[u]) x[u] = img[p];
-            }
+            if (COST == CMAX_COST_VARIANCE) x[u] = img[p < npix ? p : npix - 1u];  // unconditional: see pin()
+        }
+        if (COST == CMAX_COST_VARIANCE) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pin(x[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = in[u] ? x[u] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
