@@ -81,6 +81,7 @@ RAW_LINES = 32
 RAW_DOUBLES = RAW_LINES * 16
 PROF_CLASSES = 6
 ECOMM = -5
+ENODEV = -4
 
 # every symbol include/cmax_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -119,6 +120,7 @@ SIGNATURES = {
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "cmax_set_deterministic": (c_int, [c_vp, c_int]),
     "cmax_get_deterministic": (c_int, [c_vp, ctypes.POINTER(c_int)]),
+    "cmax_comm_available": (c_int, [ctypes.c_char_p, c_int]),
     "cmax_comm_unique_id": (c_int, [c_vp]),
     "cmax_comm_init": (c_int, [c_vp, c_vp, c_int, c_int]),
     "cmax_comm_destroy": (c_int, [c_vp]),

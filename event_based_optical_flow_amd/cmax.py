@@ -341,12 +341,25 @@ class CMaxHandle:
         return bool(v.value)
 
     # -- in-library collectives (RCCL over xGMI, see distributed.py) -------------------------------------
-    def comm_init(self, group=None, force_rccl: bool = False):
+    def comm_available(self) -> Tuple[bool, str]:
+        """(RCCL can be bound in this process, path of the shared object it was bound from) -- cmax_comm_available, a LOCAL
+        call: ranks agree on it before any of them enters the blocking cmax_comm_init."""
+        buf = ctypes.create_string_buffer(1024)
+        rc = self._lib.cmax_comm_available(buf, len(buf))
+        return rc == 0, buf.value.decode("utf-8", "replace")
+
+    def comm_init(self, group=None, force_rccl: bool = False, timeout_s: float = 120.0):
         """Give this handle an RCCL communicator over the ranks of the torch.distributed `group` (default: the
         world): rank 0 draws the rendezvous id (cmax_comm_unique_id), torch.distributed ships it, every rank
         calls cmax_comm_init.  After that `evaluate_dist` needs no torch.distributed call at all.
         World size 1: no communicator (evaluate_dist == evaluate) unless force_rccl, which makes a real
-        1-rank communicator so that the N > 1 enqueue sequence can be exercised on one GPU."""
+        1-rank communicator so that the N > 1 enqueue sequence can be exercised on one GPU.
+        No rank can be left waiting for another: (1) every rank first checks LOCALLY that RCCL can be bound and the
+        ranks agree on that with one MIN all-reduce -- nobody enters ncclCommInitRank unless everybody will; (2) the blocking
+        cmax_comm_init runs under a watchdog (`timeout_s`): a rank whose peers never arrive raises instead of hanging, and
+        the caller (TimeSlicedObjective) then agrees on the torch.distributed fall-back."""
+        import threading
+
         import torch.distributed as dist
 
         have = dist.is_available() and dist.is_initialized()
@@ -355,21 +368,47 @@ class CMaxHandle:
         if world == 1 and not force_rccl:
             check(self._lib.cmax_comm_init(self._h, None, 1, 0))
             return self
-        ids, err = [None], None
-        if rank == 0:
+        ok, path = self.comm_available()
+        err = None if ok else _lib.CmaxError(_lib.ENODEV, self._lib.cmax_last_error().decode("utf-8", "replace"))
+        ids = [None]
+        if rank == 0 and ok:
             buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
             try:
                 check(self._lib.cmax_comm_unique_id(buf))
                 ids = [buf.raw]
-            except _lib.CmaxError as e:  # the other ranks wait in the broadcast below: tell them before raising
-                err = e
+            except _lib.CmaxError as e:  # the other ranks wait in the exchange below: tell them before raising
+                err, ok = e, False
         if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)  # (1) everybody, or nobody
+            if int(flag.item()) == 0:
+                raise err if err is not None else _lib.CmaxError(_lib.ENODEV, "RCCL is not available on another rank")
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(ids, src=src, group=group)
+        elif err is not None:
+            raise err
         if ids[0] is None:
-            raise err if err is not None else _lib.CmaxError(_lib.ECOMM, "rank 0 could not draw an RCCL rendezvous id")
-        with torch.cuda.device(self.device):
-            check(self._lib.cmax_comm_init(self._h, ids[0], world, rank))
+            raise _lib.CmaxError(_lib.ECOMM, "rank 0 could not draw an RCCL rendezvous id")
+        out = {}
+
+        def init():  # (2) ncclCommInitRank blocks until all ranks have called it; ctypes releases the GIL meanwhile
+            try:
+                with torch.cuda.device(self.device):  # the current HIP device is per thread
+                    out["rc"] = self._lib.cmax_comm_init(self._h, ids[0], world, rank)
+                    out["msg"] = self._lib.cmax_last_error() if out["rc"] else b""
+            except Exception as e:  # pragma: no cover
+                out["exc"] = e
+
+        t = threading.Thread(target=init, name="cmax_comm_init", daemon=True)
+        t.start()
+        t.join(timeout_s)
+        if t.is_alive():
+            raise _lib.CmaxError(_lib.ECOMM, f"cmax_comm_init did not return within {timeout_s:.0f} s: a rank never reached ncclCommInitRank")
+        if "exc" in out:
+            raise out["exc"]
+        if out.get("rc", 0):
+            raise _lib.CmaxError(out["rc"], (out.get("msg") or b"").decode("utf-8", "replace"))
+        self.rccl_path = path
         return self
 
     def comm_info(self) -> Tuple[int, int, int]:

@@ -21,6 +21,8 @@ __attribute__((visibility("hidden"))) void comm_destroy(Comm *c);
 __attribute__((visibility("hidden"))) int comm_nranks(const Comm *c);
 __attribute__((visibility("hidden"))) int comm_rank(const Comm *c);
 __attribute__((visibility("hidden"))) int comm_version();
+// 0 if RCCL can be bound in this process (binds it), else CMAX_ENODEV; path_out: the shared object the entry points came from
+__attribute__((visibility("hidden"))) int comm_available(char *path_out, int cap);
 // in-place all-reduce of `count` elements at `buf` (device), enqueued on `s`
 __attribute__((visibility("hidden"))) int comm_allreduce(Comm *c, void *buf, size_t count, CommType type, CommOp op, hipStream_t s);
 // several in-place all-reduces as ONE grouped RCCL call (ncclGroupStart / End): one launch, one synchronisation of the ranks

@@ -25,6 +25,7 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
     std::string why;
+    std::string path;  // file the bound ncclGetVersion lives in (dladdr): torch's copy when the process holds one
 };
 
 RcclApi g_api;
@@ -65,6 +66,8 @@ void load_api() {
     CMAX_SYM(GroupEnd, "ncclGroupEnd")
     CMAX_SYM(GetErrorString, "ncclGetErrorString")
 #undef CMAX_SYM
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(g_api.GetVersion), &info) && info.dli_fname) g_api.path = info.dli_fname;
     g_api.ok = true;
 }
 
@@ -95,9 +98,20 @@ ncclRedOp_t nccl_op(CommOp o) { return o == kCommMin ? ncclMin : (o == kCommMax 
 struct Comm {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    hipStream_t last_stream = nullptr;  // stream of the last collective (synchronised before the communicator is destroyed)
+    bool used = false;
 };
 
 static_assert(sizeof(ncclUniqueId) == CMAX_COMM_ID_BYTES, "cmax_hip.h's CMAX_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+int comm_available(char *path_out, int cap) {
+    int rc = api_ready();
+    if (path_out && cap > 0) {
+        std::strncpy(path_out, rc ? "" : g_api.path.c_str(), (size_t)cap - 1);
+        path_out[cap - 1] = '\0';
+    }
+    return rc;
+}
 
 int comm_version() {
     if (api_ready()) return 0;
@@ -134,6 +148,8 @@ int comm_create(const void *id128_host, int nranks, int rank, Comm **out) {
 
 void comm_destroy(Comm *c) {
     if (!c) return;
+    // collectives of prepared calls may still be queued: ncclCommDestroy on a busy communicator is undefined
+    if (c->used) (void)hipStreamSynchronize(c->last_stream);
     if (c->comm && g_api.ok) (void)g_api.CommDestroy(c->comm);
     delete c;
 }
@@ -143,6 +159,8 @@ int comm_rank(const Comm *c) { return c ? c->rank : 0; }
 
 int comm_allreduce(Comm *c, void *buf, size_t count, CommType type, CommOp op, hipStream_t s) {
     if (!c || count == 0) return 0;  // a 1-rank communicator still goes through RCCL (world-1 tests run the real path)
+    c->last_stream = s;
+    c->used = true;
     CMAX_CHECK_RCCL(g_api.AllReduce(buf, buf, count, nccl_type(type), nccl_op(op), c->comm, s));
     return 0;
 }
@@ -150,6 +168,8 @@ int comm_allreduce(Comm *c, void *buf, size_t count, CommType type, CommOp op, h
 int comm_allreduce_group(Comm *c, void *const *bufs, const size_t *counts, const CommType *types, int n, CommOp op, hipStream_t s) {
     if (!c || n == 0) return 0;
     if (n == 1) return comm_allreduce(c, bufs[0], counts[0], types[0], op, s);
+    c->last_stream = s;
+    c->used = true;
     CMAX_CHECK_RCCL(g_api.GroupStart());
     for (int i = 0; i < n; ++i) {
         if (counts[i] == 0) continue;

@@ -2838,6 +2838,8 @@ int cmax_get_deterministic(cmax_handle_t h, int *enabled) {
     return 0;
 }
 
+int cmax_comm_available(char *path_host, int path_capacity) { return comm_available(path_host, path_capacity); }
+
 int cmax_comm_unique_id(void *id_host) {
     CMAX_REQUIRE(id_host != nullptr, "comm_unique_id: id_host");
     return comm_unique_id(id_host);

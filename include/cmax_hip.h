@@ -307,6 +307,11 @@ int cmax_objective_finish(cmax_handle_t h, const cmax_objective_t *desc_host, co
  * RCCL is bound at run time (the librccl already in the process, i.e. torch's, else ROCm's); a handle
  * without a communicator -- or with nranks == 1 -- never touches it.
  * ============================================================================================= */
+/* 0 if RCCL can be bound in this process (and binds it), CMAX_ENODEV otherwise -- a LOCAL call, no rank waits for another:
+ * the ranks agree on it (by whatever transport carries the rendezvous id) BEFORE any of them enters cmax_comm_init, which
+ * blocks in ncclCommInitRank until every rank has called it.  path_host (optional, path_capacity bytes): the shared
+ * object the entry points were resolved from -- torch's bundled librccl when the process already holds one.       */
+int cmax_comm_available(char *path_host, int path_capacity);
 #define CMAX_COMM_ID_BYTES 128
 /* rank 0: a fresh rendezvous id (ncclGetUniqueId) into id_host[128]; ship it to the other ranks
  * by any means (torch.distributed broadcast, a file, MPI).                                      */

@@ -222,3 +222,33 @@ def test_two_dof_single_exchange_path(world1_nccl, cost, theta, pad, frac, norma
         ref = orc.objective(ev, theta, "2d-translation", size, cost=cost, sigma=0, outer_padding=pad)
         assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
         assert rel_max(grad_d.cpu().numpy(), ref["grad"]) <= TOL
+
+
+def test_eight_ranks_sharing_one_gpu():
+    """The N = 8 run as far as one GPU can take it: eight processes under torch.distributed.run, each with its
+    time slice of one batch (one of them EMPTY in two cases), global extremes, C1 and C2 as collectives (gloo: RCCL refuses
+    eight ranks on one device) -- the 8-rank loss and gradient must equal the single-handle evaluation of the whole batch,
+    and be the same on every rank.  tests/_dist_worker.py is the rank program."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "2"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["world"] == 8 and len(out["cases"]) == 5
+    for c in out["cases"]:
+        print(f"[8 ranks] {c['model']} {c['cost']} empty={c['empty']}: loss {c['loss']:.9g} vs {c['loss_single']:.9g}, "
+              f"grad diff {c['grad_rel_diff']:.2e}, spread over ranks {c['spread_over_ranks']:.1e}")
+        assert abs(c["loss"] - c["loss_single"]) <= 2e-6 * abs(c["loss_single"])
+        assert c["grad_rel_diff"] <= 2e-5  # fp32 atomics / another summation order; both are within 1e-4 of the oracle
+        assert c["spread_over_ranks"] == 0.0  # an all-reduce leaves every rank with the same bits
+        assert c["loss_spread_over_ranks"] <= 1e-12 * abs(c["loss_single"])  # evaluated redundantly per rank: fp64 summation order
