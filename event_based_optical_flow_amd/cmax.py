@@ -98,9 +98,16 @@ class CMaxHandle:
     # ------------------------------------------------------------------------------------------
     finds_time_extremes = True  # set_events(ev, None, None, ...) reduces t_min / t_max on the device
 
-    def set_events(self, events, tmin: Optional[float] = None, tmax: Optional[float] = None, time_bin: int = 0):
+    def set_events(self, events, tmin: Optional[float] = None, tmax: Optional[float] = None, time_bin: int = 0,
+                   on_dropped: str = "warn"):
         """Pack + sort one [n,4] batch (numpy or tensor, fp32/fp64).  (tmin, tmax): global batch
-        extremes when this handle only holds a time slice of the batch (multi-GPU)."""
+        extremes when this handle only holds a time slice of the batch (multi-GPU).
+        on_dropped: what to do when events were NOT packed because their source pixel lies off the sensor (or is NaN) --
+        the fused path indexes source tiles and the flow field with it; the reference's 2-DoF warp would still let such an
+        event vote if it warps into a padded image, its dense warp indexes out of bounds there -- "warn" (log),
+        "raise" (a solver that must not diverge from the reference silently: ValueError) or "ignore"."""
+        if on_dropped not in ("warn", "raise", "ignore"):
+            raise ValueError(f"on_dropped should be warn, raise or ignore. Got {on_dropped}.")
         ev = to_device_tensor(events, "events")
         if ev.dim() != 2 or ev.shape[1] != 4:
             raise ValueError(f"events must be [n, 4], got {tuple(ev.shape)}")
@@ -110,7 +117,11 @@ class CMaxHandle:
                                         float(tmin) if have else 0.0, float(tmax) if have else 0.0, int(time_bin),
                                         F._stream()))
         self.time_bin = int(time_bin)
-        dropped = self.batch_info()["dropped"]
+        dropped = self.batch_info()["dropped"] if on_dropped != "ignore" else 0
+        if dropped and on_dropped == "raise":
+            raise ValueError(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events whose source pixel is outside the "
+                             f"{self.image_size[0]} x {self.image_size[1]} sensor (or NaN); use the leaf operators (Warp + "
+                             "EventImageConverter) for such batches, or crop / pad the sensor")
         if dropped:
             logger.warning(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events: source pixel outside the "
                            f"{self.image_size[0]} x {self.image_size[1]} sensor (or NaN); the fused path cannot keep them")

@@ -2703,6 +2703,11 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
         if (rc) return rc;
     }
     rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true, raw, raw != nullptr, raw_out != nullptr);
+    if (h->mu_valid) {  // K1 summed its votes and nothing consumed (and cleared) them -- an error on the way, or a path that does
+        // not use them after all: the next evaluation must find clean accumulators
+        (void)hipMemsetAsync(h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride, 0, (size_t)4 * kMuStride * sizeof(double), s);
+        h->mu_valid = false;
+    }
     if (rc) return rc;
     h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
     h->cur_buf ^= 1;
@@ -2819,13 +2824,25 @@ int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *d, const void *
 
 int cmax_set_deterministic(cmax_handle_t h, int enable) {
     CMAX_REQUIRE(h != nullptr, "set_deterministic: handle");
-    if (enable && !h->img64) {
+    if (enable) {  // each buffer on its own: a failed allocation must not leave a later call believing everything is there
         const int64_t npix = (int64_t)h->Hp * h->Wp;
-        int rc = dev_alloc(h, &h->img64, 5 * npix);
-        if (!rc) rc = dev_alloc(h, &h->d_imax, kStatSlots);
-        if (!rc) rc = dev_alloc(h, &h->d_det_inv_scale, 4);
-        if (rc) return rc;
-        CMAX_CHECK_HIP(hipMemset(h->img64, 0, (size_t)5 * npix * sizeof(long long)));
+        if (!h->img64) {
+            int rc = dev_alloc(h, &h->img64, 5 * npix);
+            if (rc) return rc;
+            if (hipMemset(h->img64, 0, (size_t)5 * npix * sizeof(long long)) != hipSuccess) {
+                dev_free(&h->img64);
+                set_error("set_deterministic: clearing the integer images failed");
+                return CMAX_ENOMEM;
+            }
+        }
+        if (!h->d_imax) {
+            int rc = dev_alloc(h, &h->d_imax, kStatSlots);
+            if (rc) return rc;
+        }
+        if (!h->d_det_inv_scale) {
+            int rc = dev_alloc(h, &h->d_det_inv_scale, 4);
+            if (rc) return rc;
+        }
     }
     h->deterministic = enable != 0;
     h->win_generation = ~(uint64_t)0;  // windows published by the other mode's K1 stay valid, but keep the state simple

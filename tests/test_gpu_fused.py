@@ -450,6 +450,11 @@ def test_dropped_events_are_counted_and_reported(caplog):
     assert abs(res[0].item() - ref["loss"]) <= 1e-3 * abs(ref["loss"])
     h.set_events(ev[keep])
     assert h.batch_info()["dropped"] == 0
+    # a solver that must not diverge from the reference silently asks for an error instead
+    with pytest.raises(ValueError, match="dropped 3"):
+        E.CMaxHandle(size).set_events(ev, on_dropped="raise")
+    with pytest.raises(ValueError):
+        E.CMaxHandle(size).set_events(ev, on_dropped="sometimes")
 
 
 def test_prepared_call_equals_evaluate_and_follows_the_motion_buffer():
