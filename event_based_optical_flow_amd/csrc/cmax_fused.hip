@@ -754,21 +754,22 @@ __device__ __forceinline__ void write_result(const ObjParams &op, const double *
     }
 }
 
-template <int COST>
-__global__ void __launch_bounds__(256)
+// THR: 256, or 1024 in deterministic mode (kStatSub workgroups, one per accumulator: they have to be large)
+template <int COST, int THR = 256>
+__global__ void __launch_bounds__(THR)
 k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double *__restrict__ stat_slot, float *__restrict__ zero_img,
         float4 *__restrict__ zero_extra, int64_t n_extra4, int64_t bs = 0) {
-    __shared__ double smem[2 * 4];
+    __shared__ double smem[2 * (THR / 64)];
     img += blockIdx.y * bs;  // blockIdx.y: image of a batch (element stride bs)
     stat_slot += blockIdx.y * kStatStride;
     if (zero_img) zero_img += blockIdx.y * bs;
     // the flow-gradient buffer K3 accumulates into is cleared here (a hipMemsetAsync node costs 4-5 us)
-    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gthreads = (int64_t)gridDim.x * 256;
+    const int64_t gtid = (int64_t)blockIdx.x * THR + threadIdx.x, gthreads = (int64_t)gridDim.x * THR;
     const unsigned npix = (unsigned)H * (unsigned)W;
     const int i0 = omit ? 1 : 0;
-    const unsigned stride = gridDim.x * 256u;
+    const unsigned stride = gridDim.x * (unsigned)THR;
     double v[2] = {0.0, 0.0};
-    for (unsigned base = blockIdx.x * 256u + threadIdx.x; base < npix; base += 4u * stride) {
+    for (unsigned base = blockIdx.x * (unsigned)THR + threadIdx.x; base < npix; base += 4u * stride) {
         float x[4];
         bool in[4];
 #pragma unroll
@@ -1354,11 +1355,18 @@ k_gimage_tan(const float *__restrict__ img, const float *__restrict__ dimg, ObjP
 // deterministic mode: fixed-point conversions
 // ---------------------------------------------------------------------------------------------
 // power-of-two scale s with  bound * n * s < 2^61: n terms of magnitude <= bound fit a 64-bit accumulator
+// (n counted as at least 2048: a single term then stays below 2^50 and det_fixed's conversion is exact)
 __device__ __forceinline__ double det_scale(double bound, long long n) {
     int e = 0;
-    (void)frexp(bound * (double)(n > 0 ? n : 1), &e);  // bound n = f 2^e, f in [0.5, 1); 0 -> e = 0
+    (void)frexp(bound * (double)(n > 2048 ? n : 2048), &e);  // bound n = f 2^e, f in [0.5, 1); 0 -> e = 0
     if (!(bound >= 0.0) || e > 1000) e = 1000;         // NaN / inf: any finite scale
     return ldexp(1.0, 60 - e);
+}
+// rint(x * s) as a 64-bit integer for |x s| < 2^51: x s + 1.5 2^52 carries the rounded integer in its low mantissa bits (one fma
+// + a 64-bit subtraction; __double2ll_rn is a ~25-instruction sequence on gfx950, twice per event in the deterministic K3)
+__device__ __forceinline__ long long det_fixed(double x, double s) {
+    const double magic = 6755399441055744.0;  // 1.5 * 2^52
+    return __double_as_longlong(fma(x, s, magic)) - __double_as_longlong(magic);
 }
 __device__ __forceinline__ void atomic_add_i64(long long *p, long long v) {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);  // two's complement: wrap-around add
@@ -1381,16 +1389,22 @@ __global__ void __launch_bounds__(256) k_fixed_to_image(FixedArgs fa, int64_t np
 
 // max |image| of one statistics slot (order-free: integer max of the magnitude bits); imax[slot] zeroed by the caller
 __global__ void __launch_bounds__(256) k_image_absmax(ImgArgs ia, int64_t npix, int slot0, unsigned *__restrict__ imax) {
+    // one atomicMax per WORKGROUP on the image's word, and at most 256 workgroups per image: same-address atomics serialise at
+    // ~12 ns each -- one per wave of a 1200-workgroup grid was 56 of the deterministic cfg3 evaluation's 225 us
+    __shared__ unsigned s_m[4];
     const float *__restrict__ img = ia.in[blockIdx.y];
     unsigned m = 0u;
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256)
         m = max(m, __float_as_uint(img[p]) & 0x7FFFFFFFu);
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, kWave));
-    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(&imax[slot0 + blockIdx.y], m);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_m[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m) atomicMax(&imax[slot0 + blockIdx.y], m);
+    }
 }
-
-// fixed-point flow gradient -> fp32 (x 1 / scale), accumulators left zero
 __global__ void __launch_bounds__(256) k_fixed_to_grad(long long *__restrict__ g64, float *__restrict__ grad, int64_t n, const double *__restrict__ inv_scale) {
     const double is = inv_scale[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -1821,7 +1835,12 @@ static int launch_stats(cmax_handle_s *h, int cost, const float *img, int omit, 
     double *stat_slot = h->d_stat + slot * kStatStride;
     ProfScope prof(h, kProfStats, s);
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (cost == CMAX_COST_VARIANCE)
+        if (h->deterministic) {  // kStatSub workgroups of 1024 threads: every accumulator is written once, the summation order is fixed
+            if (cost == CMAX_COST_VARIANCE)
+                hipLaunchKernelGGL((k_stats<CMAX_COST_VARIANCE, 1024>), dim3(grid), dim3(1024), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img, (float4 *)zero_extra, n_extra / 4);
+            else
+                hipLaunchKernelGGL((k_stats<CMAX_COST_GRADMAG, 1024>), dim3(grid), dim3(1024), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img, (float4 *)zero_extra, n_extra / 4);
+        } else if (cost == CMAX_COST_VARIANCE)
             hipLaunchKernelGGL(k_stats<CMAX_COST_VARIANCE>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img, (float4 *)zero_extra, n_extra / 4);
         else
             hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, dim3(grid), dim3(256), 0, s, img, h->Hp, h->Wp, omit, nsub, stat_slot, zero_img, (float4 *)zero_extra, n_extra / 4);
@@ -2472,7 +2491,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         CMAX_CHECK_HIP(hipMemsetAsync(h->d_imax, 0, kStatSlots * sizeof(unsigned), s));
         ImgArgs im = {};
         for (int k = 0; k < d->n_ref; ++k) im.in[k] = h->last_iwe[k];
-        hipLaunchKernelGGL(k_image_absmax, dim3(stream_grid(npix, 256), d->n_ref), dim3(256), 0, s, im, npix, 0, h->d_imax);
+        hipLaunchKernelGGL(k_image_absmax, dim3(std::min(stream_grid(npix, 1024), 256), d->n_ref), dim3(256), 0, s, im, npix, 0, h->d_imax);
         CMAX_CHECK_LAUNCH();
         if (fold == kFoldNone) {  // dL/dIWE with its chain factor: k_gimage on the (blurred) image, then the blur transpose
             if (d->sigma > 0 && !h->Gt_det) {
