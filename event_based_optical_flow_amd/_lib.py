@@ -121,6 +121,7 @@ SIGNATURES = {
     "cmax_set_deterministic": (c_int, [c_vp, c_int]),
     "cmax_get_deterministic": (c_int, [c_vp, ctypes.POINTER(c_int)]),
     "cmax_comm_available": (c_int, [ctypes.c_char_p, c_int]),
+    "cmax_comm_set_c2_bands": (c_int, [c_vp, c_int]),
     "cmax_comm_unique_id": (c_int, [c_vp]),
     "cmax_comm_init": (c_int, [c_vp, c_vp, c_int, c_int]),
     "cmax_comm_destroy": (c_int, [c_vp]),

@@ -422,6 +422,11 @@ class CMaxHandle:
         self.rccl_path = path
         return self
 
+    def comm_set_c2_bands(self, bands: int):
+        """cmax_comm_set_c2_bands: dense objectives on owned groups all-reduce the gradient in `bands` row bands behind K3."""
+        check(self._lib.cmax_comm_set_c2_bands(self._h, int(bands)))
+        return self
+
     def comm_info(self) -> Tuple[int, int, int]:
         """(nranks, rank, RCCL version) of the handle's communicator; (1, 0, 0) without one."""
         n, r, v = ctypes.c_int(1), ctypes.c_int(0), ctypes.c_int(0)

@@ -212,6 +212,12 @@ struct cmax_handle_s {
     double *d_tanpart = nullptr;           // [4][kTanBlocks][6] partial sums of k_tan_stats_var
     // time-sliced multi-GPU evaluation: this rank's RCCL communicator (cmax_comm_init), or null
     cmax::Comm *comm = nullptr;
+    // C2 in row bands behind K3 (cmax_comm_set_c2_bands): the owned-group K3 of a dense objective is launched band by band (whole
+    // tile rows) and every band's rows of the gradient are all-reduced on a second stream while the next band's K3 runs
+    int c2_bands = 1;
+    std::vector<int> row_seg_start;  // [ntr + 1] first segment of every source tile row (owned work lists only)
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> band_ev;  // [bands + 1]
     // deterministic mode (cmax_set_deterministic): every accumulation that depends on the order of events, workgroups or
     // atomics is done in integers (exact, associative) -- bit-identical IWE, loss and gradient from run to run
     bool deterministic = false;
@@ -1615,14 +1621,19 @@ static int grad_threads(const cmax_handle_s *h, int model) {
     return (force ? force >= 512 : h->nseg > 512) ? 512 : 256;
 }
 
+// seg0 / seg_n: sub-range of the work list (a band of tile rows, see cmax_comm_set_c2_bands); seg_n < 0 = the whole list.  The
+// kernels only see a shifted list (RefArgs::win is shifted by the caller).
 template <int MODEL>
 static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, int fold,
-                        const ObjParams &op, double *gpart, float *gflow, double *result, bool owned, hipStream_t s) {
-    const dim3 grid(8 * ((h->nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref);
+                        const ObjParams &op, double *gpart, float *gflow, double *result, bool owned, hipStream_t s, int seg0 = 0,
+                        int seg_n = -1) {
+    const int4 *segs = h->d_segs + seg0;
+    const int nseg = seg_n < 0 ? h->nseg : seg_n;
+    const dim3 grid(8 * ((nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref);
     ProfScope prof(h, kProfGrad, s);
     if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
 #define CMAX_LAUNCH_DET(FRAC, FOLD) \
-    hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
+    hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result)
         if (h->has_frac) {
             if (fold == kFoldStats) CMAX_LAUNCH_DET(true, kFoldStats);
             else CMAX_LAUNCH_DET(true, kFoldNone);
@@ -1638,7 +1649,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     // owned groups (dense / voxel, one reference time, group-aligned work list): LDS accumulators + plain stores
     const bool strided = MODEL == CMAX_MODEL_DENSE && !(h->long_runs && h->n_time_bin == 0);
 #define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, VARIANT) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra, op, h->d_stat, gpart, gflow, result)
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result)
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
     do {                                                                      \
         if constexpr (MODEL == CMAX_MODEL_DENSE) {                            \
@@ -1952,9 +1963,11 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         for (int g = 0; g < ngroups && fits; ++g) fits = group_start[g + 1] - group_start[g] <= kSegMax;
         h->owned = fits;
     }
+    h->row_seg_start.clear();
     if (h->owned) {
         const int span_max = T == 1 ? 3 : kAccCells / 256, row_groups = h->ntc * T;
         for (int r0 = 0; r0 < ngroups; r0 += row_groups) {
+            h->row_seg_start.push_back((int)segs.size());
             int g = r0;
             while (g < r0 + row_groups) {
                 const int gs = g;
@@ -1966,6 +1979,7 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
                 segs.push_back(make_int4(group_start[gs], cnt, gs, g - gs));
             }
         }
+        h->row_seg_start.push_back((int)segs.size());
     }
     int begin = 0, count = 0, row_of_begin = -1, g0 = 0, g_last = 0;
     auto close = [&]() {
@@ -2150,6 +2164,8 @@ int cmax_destroy(cmax_handle_t h) {
     if (!h) return 0;
     comm_destroy(h->comm);
     h->comm = nullptr;
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    for (hipEvent_t e : h->band_ev) (void)hipEventDestroy(e);
     dev_free(&h->tan);
     dev_free(&h->d_tanpart);
     dev_free(&h->img64);
@@ -2371,7 +2387,7 @@ static bool deferred_applies(const cmax_handle_s *h, const cmax_objective_t *d, 
 
 static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
                             float *zero_next, double *result, void *grad, hipStream_t s, bool reuse_windows, double *raw = nullptr,
-                            bool raw_is_reset = false, bool raw_only = false) {
+                            bool raw_is_reset = false, bool raw_only = false, cmax::Comm *c2_comm = nullptr, bool *c2_done = nullptr) {
     int rc = 0;
     const int Hp = h->Hp, Wp = h->Wp;
     const int64_t npix = (int64_t)Hp * Wp;
@@ -2573,6 +2589,41 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     const EvView ev = ev_view(h);
     const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
     double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
+    // C2 in row bands (cmax_comm_set_c2_bands): dense objective on an owned work list under a communicator.  The owned K3 STORES
+    // every gradient element of its segments' tiles, so after the launch that covers tile rows [a, b) the pixel rows [16 a, 16 b)
+    // of both channels are final on this rank: they are all-reduced on the handle's second stream while the caller's stream
+    // already runs the next band's K3.  One event per band hands the rows over, one event hands the reduced gradient back.
+    const int bands = (c2_comm && owned && d->model == CMAX_MODEL_DENSE && (int)h->row_seg_start.size() == h->ntr + 1)
+                          ? std::min(h->c2_bands, h->ntr) : 1;
+    if (bands > 1) {
+        if (!h->comm_stream) CMAX_CHECK_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        while ((int)h->band_ev.size() < bands + 1) {
+            hipEvent_t e = nullptr;
+            CMAX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->band_ev.push_back(e);
+        }
+        const int64_t hw = (int64_t)h->H * h->W;
+        for (int b = 0; b < bands; ++b) {
+            const int tr0 = (int)((int64_t)h->ntr * b / bands), tr1 = (int)((int64_t)h->ntr * (b + 1) / bands);
+            const int s0 = h->row_seg_start[tr0], s1 = h->row_seg_start[tr1];
+            RefArgs rb = ra;
+            if (rb.win) rb.win += s0;  // (one reference time: the windows of segment i sit at win[i])
+            if (s1 > s0) launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, rb, d->n_ref, fold, op, nullptr, (float *)grad, b == 0 ? res : nullptr, owned, s, s0, s1 - s0);
+            CMAX_CHECK_LAUNCH();
+            CMAX_CHECK_HIP(hipEventRecord(h->band_ev[b], s));
+            CMAX_CHECK_HIP(hipStreamWaitEvent(h->comm_stream, h->band_ev[b], 0));
+            const int r0 = tr0 * kTile, r1 = std::min(tr1 * kTile, h->H);
+            void *bufs[2] = {(float *)grad + (int64_t)r0 * h->W, (float *)grad + hw + (int64_t)r0 * h->W};
+            const size_t counts[2] = {(size_t)(r1 - r0) * h->W, (size_t)(r1 - r0) * h->W};
+            const CommType types[2] = {kCommF32, kCommF32};
+            rc = comm_allreduce_group(c2_comm, bufs, counts, types, 2, kCommSum, h->comm_stream);
+            if (rc) return rc;
+        }
+        CMAX_CHECK_HIP(hipEventRecord(h->band_ev[bands], h->comm_stream));
+        CMAX_CHECK_HIP(hipStreamWaitEvent(s, h->band_ev[bands], 0));
+        if (c2_done) *c2_done = true;
+        return 0;
+    }
     switch (d->model) {
         case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, deferred ? raw : h->d_gpart, nullptr, res, false, s); break;
         case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
@@ -2721,7 +2772,9 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
         rc = comm_allreduce(comm, cur, (size_t)n_images * npix, kCommF32, kCommSum, s);
         if (rc) return rc;
     }
-    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true, raw, raw != nullptr, raw_out != nullptr);
+    bool c2_done = false;  // the gradient was all-reduced in row bands behind K3 already
+    rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true, raw, raw != nullptr, raw_out != nullptr,
+                          dist && grad && !raw_out ? comm : nullptr, &c2_done);
     if (h->mu_valid) {  // K1 summed its votes and nothing consumed (and cleared) them -- an error on the way, or a path that does
         // not use them after all: the next evaluation must find clean accumulators
         (void)hipMemsetAsync(h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride, 0, (size_t)4 * kMuStride * sizeof(double), s);
@@ -2730,7 +2783,7 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     if (rc) return rc;
     h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
     h->cur_buf ^= 1;
-    if (dist && grad && !raw_out) {  // C2
+    if (dist && grad && !raw_out && !c2_done) {  // C2
         ProfScope prof(h, kProfComm, s);
         rc = comm_allreduce(comm, grad, (size_t)gcount, d->model == CMAX_MODEL_2DOF ? kCommF64 : kCommF32, kCommSum, s);
         if (rc) return rc;
@@ -2871,6 +2924,12 @@ int cmax_set_deterministic(cmax_handle_t h, int enable) {
 int cmax_get_deterministic(cmax_handle_t h, int *enabled) {
     CMAX_REQUIRE(h != nullptr && enabled != nullptr, "get_deterministic");
     *enabled = h->deterministic ? 1 : 0;
+    return 0;
+}
+
+int cmax_comm_set_c2_bands(cmax_handle_t h, int bands) {
+    CMAX_REQUIRE(h != nullptr && bands >= 1 && bands <= 64, "comm_set_c2_bands: bands must be in 1..64");
+    h->c2_bands = bands;
     return 0;
 }
 

@@ -328,6 +328,12 @@ int cmax_comm_info(cmax_handle_t h, int *nranks, int *rank, int *rccl_version);
 /* In-place all-reduce of a device buffer on the handle's communicator (dtype CMAX_F32 / CMAX_F64;
  * op 0 sum, 1 min, 2 max) -- e.g. (t_min, -t_max) with op min to agree on the batch extremes.   */
 int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, int op, cmax_stream_t stream);
+/* Overlap of the gradient exchange with the gather (dense objectives on a group-aligned work list, cmax_batch_info's
+ * owned_groups): with bands > 1 cmax_objective_dist launches its gathering kernel in `bands` bands of source-tile rows and
+ * all-reduces every band's rows of the gradient on a second stream of the handle while the next band is gathered (events
+ * order the two streams; the caller's stream continues after the last band is reduced).  bands = 1 (default): one launch,
+ * one all-reduce behind it.  Results are the same.                                                */
+int cmax_comm_set_c2_bands(cmax_handle_t h, int bands);
 /* One evaluation of the whole (time-sliced) batch: same arguments and results as cmax_objective,
  * the same on every rank (the gradient bit for bit; the loss up to fp64 summation order when a rank
  * holds no events).  A rank may hold zero events.  Without a communicator: == cmax_objective.   */

@@ -252,3 +252,34 @@ def test_eight_ranks_sharing_one_gpu():
         assert c["grad_rel_diff"] <= 2e-5  # fp32 atomics / another summation order; both are within 1e-4 of the oracle
         assert c["spread_over_ranks"] == 0.0  # an all-reduce leaves every rank with the same bits
         assert c["loss_spread_over_ranks"] <= 1e-12 * abs(c["loss_single"])  # evaluated redundantly per rank: fp64 summation order
+
+
+@pytest.mark.parametrize("cost,sigma", [("image_variance", 0.0), ("gradient_magnitude", 1.0)])
+def test_gradient_exchange_in_row_bands(world1_nccl, cost, sigma):
+    """cmax_comm_set_c2_bands: the owned dense K3 launched in bands of tile rows, every band's gradient rows all-reduced on
+    the handle's second stream behind it (real RCCL calls on a 1-rank communicator: the enqueue sequence, the events between
+    the two streams and the sub-range launches are those of an N-GPU run) -- same loss and gradient as one launch + one
+    all-reduce, and as the oracle."""
+    size, n = (288, 352), 700_000  # 6.9 events per pixel: every 16 x 16 tile below one segment -> owned groups
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=41)
+    flow = E.utils.generate_smooth_flow(size, 15, seed=42)
+    h = E.CMaxHandle(size).set_events(ev)
+    assert h.batch_info()["owned_groups"]
+    desc = E.make_descriptor(cost, "dense-flow", sigma=sigma)
+    h.comm_init(force_rccl=True)
+    res1, grad1 = h.evaluate_dist(desc, flow)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost=cost, sigma=int(sigma))
+    for bands in (2, 5, 64):
+        h.comm_set_c2_bands(bands)
+        for _ in range(2):
+            res_b, grad_b = h.evaluate_dist(desc, flow)
+        torch.cuda.synchronize()
+        assert abs(res_b[0].item() - res1[0].item()) <= 1e-6 * abs(res1[0].item())
+        assert rel_max(grad_b.cpu().numpy(), grad1.cpu().numpy()) <= 2e-6, bands
+        assert abs(res_b[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+        err = np.abs(grad_b.double().cpu().numpy() - ref["grad"])
+        assert (err > TOL * np.abs(ref["grad"]).max()).sum() <= 4  # (cell-border events of a 700k-event batch: tests/_border.py)
+    h.comm_set_c2_bands(1)
+    with pytest.raises(E._lib.CmaxError):
+        h.comm_set_c2_bands(0)
+    h.comm_destroy()
