@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
-for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
+for wl in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm"):
     f = os.path.join(src, "refresh", "kernel_stats_%s.txt" % wl)
     if os.path.exists(f):
         with open(os.path.join(dst, "%s_kernel_stats_%s.txt" % (tag, wl)), "w") as out:
@@ -38,9 +38,9 @@ if os.path.exists(f):
                   "# native = one cmax_patch_plan_* call; autograd = the same kernels chained by torch.autograd.\n"
                   "# reference (torch-CPU fp64, BASELINE.md): 126 / 231 ms plain, 294 / 1098 ms Burgers (value+grad / hvp)\n")
         out.writelines(lines)
-short = {"k_vote": "vote", "k_stats": "stats", "k_gimage": "gimage", "k_grad": "grad", "k_finish": "finish", "k_finish_deferred": "finish",
+short = {"k_vote": "vote", "k_stats": "stats", "k_gimage": "gimage", "k_grad": "grad", "k_finish": "finish", "k_finish_deferred": "finish", "k_finish_raw": "finish",
          "k_stats_gimage_gm": "stats", "k_blur_stats_gimage_gm": "stats", "k_blur_stats_var": "stats", "k_gimage_blur_adj_var": "gimage", "k_blur_stats_adj_var": "stats"}
-for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
+for wl in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm"):
     f = os.path.join(src, "refresh", "pmc_%s_raw.json" % wl)
     if not os.path.exists(f):
         f = os.path.join(src, "pmc_%s.json" % wl)

@@ -2,18 +2,19 @@
 # Runs on the GPU box (via gpurun): regenerates every artifact under profiles/ that quotes a kernel duration.
 # Outputs land in gpurun_out/refresh/; copy them into profiles/ afterwards (tools/collect_profiles.py <tag>).
 export TMPDIR=/tmp
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/refresh
 mkdir -p $out
-for w in cfg2 cfg3 cfg4 cfg5; do
-  bash tools/prof_kernels.sh $w --workload $w --steps 100
+for w in cfg2 cfg3 cfg4 cfg5 cfg5_strong hbm; do
+  st=100; [ $w = hbm ] && st=20; [ $w = cfg5_strong ] && st=40
+  bash tools/prof_kernels.sh $w --workload $w --steps $st
   cp gpurun_out/prof_$w/kernel_stats.txt $out/kernel_stats_$w.txt
 done
 # the official summary of the default bench command (csv output: the default rocpd database made --stats hang here)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/stats -o $tag -- python bench.py --no-cpu-baseline --no-also --steps 200 --warmup 20 --ramp 0 > $out/rocprofv3_bench_line_cfg2.txt 2>&1
 echo "rocprofv3 --stats rc=$?"
 f=$(find gpurun_out/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/rocprofv3_kernel_stats_cfg2.csv
-for w in cfg2 cfg3 cfg4 cfg5; do
+for w in cfg2 cfg3 cfg4 cfg5 cfg5_strong hbm; do
   bash tools/prof_pmc.sh $w --workload $w
   cp gpurun_out/pmc_$w.json $out/pmc_${w}_raw.json
 done
