@@ -7,10 +7,16 @@ analytic gradient (BASELINE.json metric), on synthetic events already resident i
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): BASELINE configs[1] = cfg2 = 1M synthetic events, 346x260 (H=260, W=346), 2-DoF
-translational flow, image-variance cost + analytic gradient.  For N > 1 every rank owns one 1M-event time slice of an
-N x 1M-event batch (weak scaling); both all-reduces of an evaluation (IWE, gradient) are enqueued by libcmax_hip.so
-itself (RCCL, cmax_objective_dist).  `also` carries the other single-GPU configurations (cfg3, cfg4, a cfg5 shard)
-and, for N > 1, cfg5 = 20M events 1280x720 split into N time slices (strong scaling).
+translational flow, image-variance cost + analytic gradient.  One evaluation = K1 (warp + vote) + K3 (gather + gradient); on
+one GPU it is timed in its RAW form (config.result_form): K3 leaves 32 x 6 partial sums on the device and the consumer
+folds them on the host when it reads the result (cmax_objective_raw + cmax_finalize_raw_host) -- here once per run, exactly
+as a device-resident result was read once per run before.  `also` carries the other forms (cfg2_device_result =
+cmax_objective with its finishing launch; cfg2_host_result = cmax_objective_host, every evaluation delivered to the host
+before the next starts), the headline with blur and on a sharp image, the other single-GPU configurations (cfg3, cfg4, a
+cfg5 shard), cfg5 AS BASELINE STATES IT on one GPU (cfg5_strong: 20M events, the N = 1 point of its strong-scaling curve)
+and `hbm`: 64M events, a packed stream larger than the 256 MiB Infinity Cache.  For N > 1 every rank owns one 1M-event time
+slice of an N x 1M-event batch (weak scaling); both all-reduces of an evaluation (IWE, gradient) are enqueued by
+libcmax_hip.so itself (RCCL, cmax_objective_dist), and `also.cfg5_strong` is cfg5 split into N time slices.
 
 Timing: W warm-up steps, then `windows` (default 25) windows of EXACTLY K steps, each bracketed by barrier +
 torch.cuda.synchronize() on both sides, MAX over ranks per window; ms_per_step / value are the MEDIAN window.
@@ -22,8 +28,9 @@ One JSON line on stdout (rank 0).  Extra objects:
                 cmax_set_profiling), `dominant` names the longest one
   cpu_baseline  the CPU oracle (oracle/cmax_oracle.c, scalar C, 1 core) timed on this host on the
                 same workload -- a reported baseline, not the target; cpu_baseline_torch: the same evaluation
-                written the way the reference is (torch tensor ops + autograd, oracle/torch_cpu.py) on the
-                host's cores
+                written the way the reference is (torch tensor ops + autograd, oracle/torch_cpu.py), each row of a
+                small thread sweep in a FRESH process on every CPU the launcher allowed; CPU model and core
+                counts are printed with both
 """
 import argparse
 import json
