@@ -18,6 +18,10 @@ def minimize(fun, x0, args=(), precision="float32", method=None, hvp_type=None, 
         raise NotImplementedError("constraints are not built (no solver of the reference uses them)")
     if method in ("dogleg", "trust-exact"):
         raise NotImplementedError(f"{method} needs the full Hessian; only Hessian-vector products are built")
+    if method == "Newton-CG" and options and "gtol" in options:
+        # the reference hands Newton-CG its `gtol` (src/solver/patch_contrast_pyramid.py:300-303); SciPy's Newton-CG has no such
+        # option (its tolerance is `xtol`), ignores it and warns "Unknown solver options: gtol" on every call: same run, no warning
+        options = {k: v for k, v in options.items() if k != "gtol"}
     res = sopt.minimize(
         wrapper.get_value_and_grad,
         wrapper.get_input(x0),
