@@ -62,12 +62,10 @@ constexpr int kTile = 16;  // source-pixel tile edge of the counting sort
 constexpr int kSegMax = 2040;                 // events per segment (+1 for the even-aligned start still fits 2048);
                                               // |sum of votes| <= 2040 * 2^20 < 2^31
 constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit words (32 KiB)
-static_assert(kSegMax <= 2040, "fixed-point vote accumulation would overflow");
 constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (voxel K3): 12 (tile, bin) groups
 constexpr int kAccCellsDense = 768;           // the same for the dense K3 with owned tiles: 3 source tiles
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
-constexpr float kFix = 1048576.f;             // 2^20: votes are accumulated as signed 12.20 fixed point
-constexpr float kInvFix = 1.f / 1048576.f;
+// (votes are accumulated as signed fixed point in the LDS windows: 12.20, big segments 13.19 -- kFixNS of cmax_event_kernels.inc)
 
 struct EvView {
     const uint2 *ev;      // .x = row | col << 12 | bin << 24 ; .y = bits of fp32 tau = (t - tmin) / (tmax - tmin)
@@ -148,6 +146,8 @@ struct cmax_handle_s {
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] source pixels with >= 1 event
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
+    bool big = false;        // BIG segments: up to 4088 events each, event kernels of the b512 / b1024 namespaces (batches of >= 8M events)
+    int seg_max = 2040;      // events per segment of the current work list (kSegMax, or 4088 for big segments)
     bool owned = false;      // the work list gives every group (empty ones included) to exactly one segment, <= kAccCells / 256 groups each
     int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
@@ -1382,13 +1382,14 @@ __device__ __forceinline__ void atomic_add_i64(long long *p, long long v) {
 struct FixedArgs {
     long long *src[5];
     float *dst[5];
+    double inv_fix;  // 1 / the vote fixed point of the kernels that filled src: 2^-20, big segments 2^-19
 };
 __global__ void __launch_bounds__(256) k_fixed_to_image(FixedArgs fa, int64_t npix) {
     long long *__restrict__ src = fa.src[blockIdx.y];
     float *__restrict__ dst = fa.dst[blockIdx.y];
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
         const long long v = src[p];
-        dst[p] = (float)((double)v * (1.0 / 1048576.0));  // one rounding, of the exact sum
+        dst[p] = (float)((double)v * fa.inv_fix);  // one rounding, of the exact sum
         if (v != 0) src[p] = 0;
     }
 }
@@ -1453,6 +1454,7 @@ __global__ void __launch_bounds__(256) k_finish_det(long long *__restrict__ gpar
 
 // the event kernels, once per workgroup size
 namespace cmax {
+#define CMAX_SLOTS 2048
 #define CMAX_THREADS 256
 #define CMAX_EVENT_NS t256
 #include "cmax_event_kernels.inc"
@@ -1468,6 +1470,20 @@ namespace cmax {
 #include "cmax_event_kernels.inc"
 #undef CMAX_THREADS
 #undef CMAX_EVENT_NS
+// big segments (4088 events: cmax_handle_s::big): 512 threads x 8 events, 1024 x 4
+#undef CMAX_SLOTS
+#define CMAX_SLOTS 4096
+#define CMAX_THREADS 512
+#define CMAX_EVENT_NS b512
+#include "cmax_event_kernels.inc"
+#undef CMAX_THREADS
+#undef CMAX_EVENT_NS
+#define CMAX_THREADS 1024
+#define CMAX_EVENT_NS b1024
+#include "cmax_event_kernels.inc"
+#undef CMAX_THREADS
+#undef CMAX_EVENT_NS
+#undef CMAX_SLOTS
 
 // 2-DoF only: gradient = sum of the per-segment partials of every K3 launch (one workgroup).
 __global__ void __launch_bounds__(256)
@@ -1603,7 +1619,10 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     } while (0)
     static const int force = forced_ns("CMAX_VOTE_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (force ? force == 512 : h->nseg > 512) {  // as for K3: cfg2 (704 half-tile segments) K1 6.35 -> 5.97 us, evaluation 18.06 -> 17.38
+        if (h->big) {  // the work list holds segments of up to 4088 events: only the big-segment kernels can run it
+            if (h->has_frac) CMAX_LAUNCH_VOTE(b512, true);
+            else CMAX_LAUNCH_VOTE(b512, false);
+        } else if (force ? force == 512 : h->nseg > 512) {  // as for K3: cfg2 (704 half-tile segments) K1 6.35 -> 5.97 us, evaluation 18.06 -> 17.38
             if (h->has_frac) CMAX_LAUNCH_VOTE(t512, true);
             else CMAX_LAUNCH_VOTE(t512, false);
         } else {
@@ -1617,6 +1636,7 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 // workgroup size launch_grad picks (tuning knob CMAX_GRAD_NS aside)
 static int grad_threads(const cmax_handle_s *h, int model) {
     static const int force = forced_ns("CMAX_GRAD_NS");
+    if (h->big) return model == CMAX_MODEL_VOXEL ? 1024 : 512;
     if (force ? (force == 1024 && model == CMAX_MODEL_VOXEL) : (model == CMAX_MODEL_VOXEL && wide_groups(h))) return 1024;
     return (force ? force >= 512 : h->nseg > 512) ? 512 : 256;
 }
@@ -1632,8 +1652,11 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     const dim3 grid(8 * ((nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref);
     ProfScope prof(h, kProfGrad, s);
     if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
-#define CMAX_LAUNCH_DET(FRAC, FOLD) \
-    hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result)
+#define CMAX_LAUNCH_DET(FRAC, FOLD)                                                                                                         \
+    do {                                                                                                                                    \
+        if (h->big) hipLaunchKernelGGL((b512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(b512::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result); \
+        else hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result); \
+    } while (0)
         if (h->has_frac) {
             if (fold == kFoldStats) CMAX_LAUNCH_DET(true, kFoldStats);
             else CMAX_LAUNCH_DET(true, kFoldNone);
@@ -1690,7 +1713,13 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     }
     static const int force = forced_ns("CMAX_GRAD_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
-        if (force ? (force == 1024 && MODEL == CMAX_MODEL_VOXEL) : (MODEL == CMAX_MODEL_VOXEL && wide_groups(h))) {  // measured: voxel K3 of cfg4 22.1 us (512 threads) -> 19.3 us
+        if (h->big) {  // segments of up to 4088 events
+            if constexpr (MODEL == CMAX_MODEL_VOXEL) {
+                CMAX_LAUNCH_GRAD_NS(b1024)
+            } else {
+                CMAX_LAUNCH_GRAD_NS(b512)
+            }
+        } else if (force ? (force == 1024 && MODEL == CMAX_MODEL_VOXEL) : (MODEL == CMAX_MODEL_VOXEL && wide_groups(h))) {  // measured: voxel K3 of cfg4 22.1 us (512 threads) -> 19.3 us
             if constexpr (MODEL == CMAX_MODEL_VOXEL) {
                 CMAX_LAUNCH_GRAD_NS(t1024)
             }
@@ -1784,6 +1813,7 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
     CMAX_CHECK_LAUNCH();
     if (det) {  // exact integer sums -> fp32 images, one rounding each; the integer images are zero again afterwards
         FixedArgs fa = {};
+        fa.inv_fix = h->big ? 1.0 / 524288.0 : 1.0 / 1048576.0;
         for (int k = 0; k < n_ref; ++k) {
             fa.src[k] = ra.img64[k];
             fa.dst[k] = imgs[k];
@@ -1944,13 +1974,22 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // binned handles: 12 (tile, bin) groups, what the LDS accumulators of the voxel K3 hold -- unless every segment is
     // below kSparseSegment events anyway (then that kernel adds straight to memory): up to 3 tiles' worth of groups,
     // instead of ~100-event segments cut by the span (30k events, T = 10: 312 -> 125 segments)
+    // BIG segments for batches that fill the chip many times over (CMAX_BIG_SEG=0 / 1 overrides for A/B runs): the per-workgroup
+    // fixed costs of the event kernels are paid once per 4088 events instead of once per 2040.  Pays from ~2000 big segments on
+    // (256 CUs x 3 resident workgroups, several rounds): measured (profiles/r03_ablation.txt 8) 20M events 104.3 -> 95.0 us per
+    // evaluation, 64M events 323.6 -> 292.6; 5M events (1223 segments) 38.5 -> 38.2; below that fewer, longer workgroups LOSE
+    // (2.5M events @720p 30.6 -> 33.1, 2M-event voxel batch 31.4 -> 33.5).
+    static const int big_env = getenv("CMAX_BIG_SEG") ? atoi(getenv("CMAX_BIG_SEG")) : -1;
+    h->big = big_env >= 0 ? big_env != 0 : h->n >= (int64_t)8000000;
+    h->seg_max = h->big ? 4088 : kSegMax;
+    const int kSegCut = h->seg_max;
     int max_groups = T == 1 ? 3 : kAccCells / 256;
     const bool free_cut = h->n > (int64_t)1024 * kSegMax;
     // batches far below one full segment per CU (the solver's 30k-event slices): a workgroup walks its events
     // 8 (4) per thread, so 2040-event segments leave 15 workgroups with long serial work on a 256-CU chip.
     // Cap the segment at n / 512 (>= 256 events): cfg1-shaped K3 13 -> 5 us.
-    int seg_cap = kSegMax;
-    if (h->n < (int64_t)256 * kSegMax) seg_cap = (int)std::min<int64_t>(kSegMax, std::max<int64_t>(256, (h->n + 511) / 512));
+    int seg_cap = kSegCut;
+    if (h->n < (int64_t)256 * kSegMax) seg_cap = (int)std::min<int64_t>(kSegCut, std::max<int64_t>(256, (h->n + 511) / 512));
     if (T > 1 && seg_cap < kSparseSegment) max_groups = std::max(max_groups, 3 * T);
     std::vector<int4> segs;
     // Owned groups (batches of at least one full segment per CU whose groups all fit a segment): every group -- empty
@@ -1960,19 +1999,19 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     h->owned = false;
     if (h->n >= (int64_t)256 * kSegMax && !getenv("CMAX_NO_OWNED")) {
         bool fits = true;
-        for (int g = 0; g < ngroups && fits; ++g) fits = group_start[g + 1] - group_start[g] <= kSegMax;
+        for (int g = 0; g < ngroups && fits; ++g) fits = group_start[g + 1] - group_start[g] <= kSegCut;
         h->owned = fits;
     }
     h->row_seg_start.clear();
     if (h->owned) {
-        const int span_max = T == 1 ? 3 : kAccCells / 256, row_groups = h->ntc * T;
+        const int span_max = T == 1 ? (h->big ? 6 : 3) : kAccCells / 256, row_groups = h->ntc * T;  // dense: kAccCellsDense (x 2 for big segments)
         for (int r0 = 0; r0 < ngroups; r0 += row_groups) {
             h->row_seg_start.push_back((int)segs.size());
             int g = r0;
             while (g < r0 + row_groups) {
                 const int gs = g;
                 int cnt = 0;
-                while (g < r0 + row_groups && g - gs < span_max && cnt + (group_start[g + 1] - group_start[g]) <= kSegMax) {
+                while (g < r0 + row_groups && g - gs < span_max && cnt + (group_start[g + 1] - group_start[g]) <= kSegCut) {
                     cnt += group_start[g + 1] - group_start[g];
                     ++g;
                 }
@@ -2700,7 +2739,10 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
         const dim3 grid(8 * ((h->nseg + 7) / 8), nr);
         ProfScope prof(h, kProfVote, s);
         for (int rep = 0; rep < h->prof_repeat; ++rep) {
-            if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan2<true>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
+            if (h->big) {
+                if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan2<true>), grid, dim3(b512::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
+                else hipLaunchKernelGGL((b512::k_vote_tan2<false>), grid, dim3(b512::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
+            } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan2<true>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
             else hipLaunchKernelGGL((t256::k_vote_tan2<false>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
         }
         CMAX_CHECK_LAUNCH();
@@ -2990,7 +3032,10 @@ namespace cmax {
 template <int MODEL>
 static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, float *draw, hipStream_t s) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
-    if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+    if (h->big) {
+        if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+        else hipLaunchKernelGGL((b512::k_vote_tan<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+    } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
     else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
 }
 
@@ -2998,7 +3043,10 @@ template <int MODEL>
 static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, const float *G,
                             const float *Gp, double *gpart, float *hflow, hipStream_t s) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
-    if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    if (h->big) {
+        if (h->has_frac) hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+        else hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+    } else if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
     else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
 }
 
@@ -3069,7 +3117,7 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
         dtmax *= period > 0 ? period : 1.0;
         if (dtmax < 1e-30) dtmax = 1e-30;
         tp.d[k] = (float)dref;
-        tp.fixk[k] = (float)(1073741824.0 / ((double)kSegMax * 2.0 * dtmax));  // 2^30 / (events * max |derivative vote|)
+        tp.fixk[k] = (float)(1073741824.0 / ((double)h->seg_max * 2.0 * dtmax));  // 2^30 / (events * max |derivative vote|)
     }
     tp.fix = tp.fixk[0];
     tp.inv_fix = 1.f / tp.fix;
