@@ -283,3 +283,34 @@ def test_gradient_exchange_in_row_bands(world1_nccl, cost, sigma):
     with pytest.raises(E._lib.CmaxError):
         h.comm_set_c2_bands(0)
     h.comm_destroy()
+
+
+def test_cfg5_half_batch_through_the_communicator_path(world1_nccl):
+    """What rank 0 of `bench.py --gpus 2` runs for cfg5 (also.cfg5_strong): a 10M-event time slice at 1280x720 -- BIG segments
+    (>= 8M events: b512 kernels) on an owned work list -- through cmax_objective_dist under a real (1-rank) RCCL communicator:
+    K1 -> all-reduce -> k_stats -> K3 (kFoldStats, owned, stores) -> all-reduce, also with the gradient exchanged in row bands.
+    Against the oracle on the same 10M events, with the per-pixel cell-border bound of tests/_border.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _border import ambiguity_bound, raw_image_grad
+
+    size, n = (720, 1280), 10_000_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.025, seed=46)
+    flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
+    # extremes handed in like a rank of a time-sliced run gets them (here: the slice's own, so that the oracle sees the same batch)
+    h = E.CMaxHandle(size).set_events(torch.from_numpy(ev).cuda(), ev[:, 2].min(), ev[:, 2].max())
+    assert h.batch_info()["owned_groups"]
+    desc = E.make_descriptor("image_variance", "dense-flow")
+    h.comm_init(force_rccl=True)
+    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
+    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    gmax = np.abs(ref["grad"]).max()
+    for bands in (1, 3):
+        h.comm_set_c2_bands(bands)
+        for _ in range(2):
+            res, grad = h.evaluate_dist(desc, flow)
+        torch.cuda.synchronize()
+        err = np.abs(grad.double().cpu().numpy() - ref["grad"])
+        e_gate = (err - 1.01 * bound).max() / gmax
+        print(f"[dist 10M] bands {bands}: loss rel err {abs(res[0].item() - ref['loss']) / abs(ref['loss']):.2e}, grad gated {e_gate:.2e} ({n_amb} cell-border events)")
+        assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"]) and e_gate <= TOL
+    h.comm_destroy()
