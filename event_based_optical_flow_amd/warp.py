@@ -3,8 +3,9 @@
 Same constructor, method names, argument meaning and error behaviour as the reference so that
 callers (solvers, tests) switch by changing the import.  The arithmetic runs in
 libcmax_hip.so (cmax_warp_events / cmax_warp_events_bwd); numpy inputs are moved to the GPU and
-back.  Outside the scope: "dense-flow-voxel-optimized", which raises
-AttributeError in the reference itself (src/warp.py:422) and is unreachable from its solvers.
+back.  "dense-flow-voxel-optimized"  raises AttributeError in the reference itself
+(`self.feature_base`, src/warp.py:422) and is unreachable from its solvers; here it computes what that function
+describes -- the voxel warp on a flow propagated bin by bin with Burgers steps -- see `warp_event`.
 """
 import logging
 from typing import Optional, Tuple, Union
@@ -101,11 +102,31 @@ class Warp(object):
         Dispatch as src/warp.py:156-199; unknown models raise MotionModelKeyError."""
         if motion_model in _TRANSLATION_MODELS:
             assert motion.shape[-1] == 2
-        elif motion_model not in ("dense-flow", "dense-flow-voxel"):
+        elif motion_model not in ("dense-flow", "dense-flow-voxel", "dense-flow-voxel-optimized"):
             raise MotionModelKeyError(motion_model)
         F.direction_to_ref(direction)  # validates `direction` before touching the GPU (ValueError)
+        if motion_model == "dense-flow-voxel-optimized" and (flow_propagate_bin is None or int(flow_propagate_bin) <= 0):
+            raise ValueError("dense-flow-voxel-optimized needs flow_propagate_bin (number of time bins)")
         ev = to_device_tensor(events, "events")
         mo = to_device_tensor(motion, "motion").to(ev.dtype)
+        if motion_model == "dense-flow-voxel-optimized":
+            # warp_event_from_optical_flow_voxel_optimized (src/warp.py:398-481): `motion` is ONE flow [(b,) 2, H, W]; bin k of the
+            # flow_propagate_bin time bins is warped with the flow propagated k + 1 times by one Burgers step of 1 / n
+            # (inviscid_burger_flow_to_voxel, the step precedes the use: 440-442).  The reference never materialises the voxel;
+            # cmax_flow_step is one launch per bin on [2,H,W], so the "memory-lean" chain costs n small launches here and the
+            # warp itself is the voxel kernel.  (The reference's own function stops at `self.feature_base`, an attribute Warp
+            # does not have.)
+            n_bin = int(flow_propagate_bin)
+
+            def sequential_voxel(f):
+                steps = []
+                for _ in range(n_bin):
+                    f = F.flow_step(f, 1.0 / n_bin, "burgers")
+                    steps.append(f)
+                return torch.stack(steps)
+
+            mo = torch.stack([sequential_voxel(m) for m in mo]) if mo.dim() == 4 else sequential_voxel(mo)
+            motion_model = "dense-flow-voxel"
         if ev.shape[-1] < 4:  # the reference's tests pass [n,3]; pad a polarity column and strip it after
             pad = ev.new_zeros(ev.shape[:-1] + (4 - ev.shape[-1],))
             ev4 = torch.cat([ev, pad], dim=-1)

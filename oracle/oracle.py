@@ -92,7 +92,21 @@ def calculate_dt(events, tref, normalize_t=True, period=None):
 # --------------------------------------------------------------------------------------------
 # a3-a6 warps.  Returns (warped[n,4], aux) ; aux holds dt and (voxel) the per-event bin.
 # --------------------------------------------------------------------------------------------
-def warp_event(events, motion, motion_model, direction="first", image_size=None, normalize_t=True):
+def voxel_from_sequential_burgers(flow, n_time_bin):
+    """The flow voxel warp_event_from_optical_flow_voxel_optimized builds on the fly (src/warp.py:438-442): bin k uses the
+    flow propagated k + 1 times by inviscid_burger_flow_to_voxel with delta_t = 1 / n_time_bin (the step comes BEFORE the use)."""
+    f = _f64(flow)
+    out = []
+    for _ in range(int(n_time_bin)):
+        f = burgers_step(f, 1.0 / n_time_bin)
+        out.append(f)
+    return np.stack(out)
+
+
+def warp_event(events, motion, motion_model, direction="first", image_size=None, normalize_t=True, flow_propagate_bin=None):
+    if motion_model == "dense-flow-voxel-optimized":  # a7: the same warp as "dense-flow-voxel" on the voxel built bin by bin
+        return warp_event(events, voxel_from_sequential_burgers(motion, flow_propagate_bin), "dense-flow-voxel", direction, image_size,
+                          normalize_t)
     ev = _ev4(events)
     n = ev.shape[0]
     tref = reftime(ev, direction)

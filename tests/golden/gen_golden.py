@@ -716,6 +716,28 @@ def gen_cfg2_fp32_reference():
     save("cfg2_fp32_reference", **out)
 
 
+def gen_warp_voxel_optimized():
+    """a7: Warp.warp_event(..., "dense-flow-voxel-optimized", flow_propagate_bin=n) -> warp_voxel_optimized.npz.  The reference's
+    function raises AttributeError at its first statement (`self.feature_base`, src/warp.py:422: Warp has feature_2dof / feature_dense
+    only), so it is run here with that ONE attribute supplied (= feature_dense, whose calculate_feature(skip=True) is what the
+    sibling voxel warp returns, src/warp.py:394-396) -- everything after that line is the reference's own code."""
+    rng = np.random.default_rng(SEED + 10)
+    H, W = 26, 34
+    ev = make_events(900, H, W, rng)
+    flow = smooth_flow(H, W, rng, 6.0)
+    out = {"events": ev, "flow": flow, "image_size": np.array([H, W]), "seed": np.array(SEED + 10), "shims": np.array(ref_import.SHIMS),
+           "note": np.array("Warp.feature_base = Warp.feature_dense supplied (missing attribute in the reference, src/warp.py:422)")}
+    w = warp.Warp((H, W), normalize_t=True)
+    w.feature_base = w.feature_dense
+    for n_bin in (4, 10):
+        for d in ["first", "middle", "last"]:
+            a = w.warp_event(torch.from_numpy(ev), torch.from_numpy(flow), "dense-flow-voxel-optimized", d, flow_propagate_bin=n_bin)[0].numpy()
+            b = w.warp_event(ev, flow, "dense-flow-voxel-optimized", d, flow_propagate_bin=n_bin)[0]
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)  # torch and numpy branches agree
+            out[f"T{n_bin}_{d}"] = a
+    save("warp_voxel_optimized", **out)
+
+
 def gen_hvp_inv():
     """Hybrid costs with an "inv" weight (src/costs/hybrid.py:51-53: the term contributes 1 / cost): value, gradient and
     vhp of the objective w.r.t. the motion, inputs of objective.npz -> hvp_inv.npz"""
@@ -798,10 +820,10 @@ def gen_core():
 
 if __name__ == "__main__":
     # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search] [solver_optimize]
-    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32]   (no argument = everything)
+    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized]   (no argument = everything)
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
                                                                     "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv", "costs_batched",
-                                                                    "solver_cfg1_variance", "cfg2_fp32"]
+                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -826,3 +848,5 @@ if __name__ == "__main__":
         gen_solver_objective_cfg1_variance()
     if "cfg2_fp32" in which:
         gen_cfg2_fp32_reference()
+    if "warp_voxel_optimized" in which:
+        gen_warp_voxel_optimized()

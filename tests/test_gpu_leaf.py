@@ -339,6 +339,28 @@ def test_motion_model_errors():
         warper.warp_event(ev, torch.zeros(2, device=DEV), "2d-translation", direction="sideways")
 
 
+@pytest.mark.parametrize("n_bin", [4, 10])
+@pytest.mark.parametrize("direction", ["first", "middle", "last"])
+def test_warp_voxel_optimized_golden(golden, n_bin, direction):
+    """a7 ("dense-flow-voxel-optimized", src/warp.py:398-481): one flow propagated bin by bin with Burgers steps (cmax_flow_step)
+    and the voxel warp kernel on it -- numpy in / numpy out and tensor in / tensor out against the reference's values, and a
+    gradient flows back to the flow through the chain."""
+    g = golden("warp_voxel_optimized")
+    size = tuple(int(v) for v in g["image_size"])
+    warper = E.Warp(size, normalize_t=True)
+    ref = g[f"T{n_bin}_{direction}"]
+    out_np, feat = warper.warp_event(g["events"], g["flow"], "dense-flow-voxel-optimized", direction, flow_propagate_bin=n_bin)
+    assert isinstance(out_np, np.ndarray) and isinstance(feat, dict)
+    np.testing.assert_allclose(out_np, ref, rtol=0, atol=1e-9)
+    flow = torch.from_numpy(g["flow"]).to(DEV).requires_grad_()
+    out_t, _ = warper.warp_event(torch.from_numpy(g["events"]).to(DEV), flow, "dense-flow-voxel-optimized", direction, flow_propagate_bin=n_bin)
+    np.testing.assert_allclose(out_t.detach().cpu().numpy(), ref, rtol=0, atol=1e-9)
+    (gflow,) = torch.autograd.grad(out_t[:, :2].sum(), flow)
+    assert gflow.shape == flow.shape and torch.isfinite(gflow).all() and float(gflow.abs().max()) > 0
+    with pytest.raises(ValueError):
+        warper.warp_event(g["events"], g["flow"], "dense-flow-voxel-optimized", direction)
+
+
 @pytest.mark.parametrize("sigma", [1, 2, 0.6])
 def test_numpy_branch_blur_golden(golden, sigma):
     """create_iwe on numpy events with sigma > 0 = scipy.ndimage.gaussian_filter (reference line 122-124)."""

@@ -120,7 +120,9 @@ def test_warp_host_helpers_and_errors():
     with pytest.raises(E.MotionModelKeyError):
         w.get_key_names("affine")
     with pytest.raises(E.MotionModelKeyError):
-        w.warp_event(np.zeros((2, 4)), np.zeros(3), "dense-flow-voxel-optimized")
+        w.warp_event(np.zeros((2, 4)), np.zeros(3), "affine")
+    with pytest.raises(ValueError):  # a7: the time-bin count is the model's parameter (src/warp.py:176)
+        w.warp_event(np.zeros((2, 4)), np.zeros((2, 100, 200)), "dense-flow-voxel-optimized")
     for lo, hi, ref, exp in ((1, 2, 1.0, (0, 1)), (0, 0.5, 0.0, (0, 1)), (-1, 1, 0.0, (-0.5, 0.5)), (-1, 1, -1.0, (0, 1))):
         ev = E.utils.generate_events(300, 100, 200, tmin=lo, tmax=hi, seed=1)
         dt = w.calculate_dt(ev, ref)

@@ -342,3 +342,14 @@ def test_oracle_on_the_bench_stream_equals_the_reference_fp64_row(golden):
     assert abs(ref["iwes"]["iwe"].sum() - float(g["f64__iwe_sum"])) <= 1e-9 * float(g["f64__iwe_sum"])
     # what the reference's fp32 evaluation makes of the same stream: outside the 1e-4 gate
     assert float(g["fp32_grad_rel_err"]) > 1e-4 and int(g["events_in_another_cell_in_fp32"]) > 0
+
+
+@pytest.mark.parametrize("n_bin", [4, 10])
+@pytest.mark.parametrize("direction", ["first", "middle", "last"])
+def test_warp_voxel_optimized(golden, n_bin, direction):
+    """a7, Warp.warp_event_from_optical_flow_voxel_optimized (src/warp.py:398-481): fixture = the reference's own code behind its
+    missing `feature_base` attribute (gen_golden.py warp_voxel_optimized)."""
+    g = golden("warp_voxel_optimized")
+    size = tuple(int(v) for v in g["image_size"])
+    w, _ = orc.warp_event(g["events"], g["flow"], "dense-flow-voxel-optimized", direction, size, flow_propagate_bin=n_bin)
+    np.testing.assert_allclose(w, g[f"T{n_bin}_{direction}"], rtol=0, atol=1e-12)
