@@ -35,6 +35,7 @@
 // fp32 per event with the integer source pixel split from the fp32 displacement (keeps the
 // bilinear fractions accurate to ulp(displacement) instead of ulp(coordinate)); fp64 reductions.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -178,6 +179,7 @@ struct cmax_handle_s {
     int64_t host_grad_bytes = 0;
     double *hp_out = nullptr;  // pinned
     int64_t hp_out_cap = 0;
+    unsigned long long host_seq = 0;  // run counter of the finishing kernel that writes into hp_out (polled by cmax_objective_host)
     int *d_ticket = nullptr;    // arrival counters of the statistics workgroups inside K3 (kFoldStatsInside): zero between launches
     double *d_musum = nullptr;  // [2 buffers][4 reference times][kMuStride] K1's sums for the blurred variance (RefArgs::musum)
     int mu_buf = 0;             // buffer the next evaluation adds into (the other one is being cleared / is clear)
@@ -1560,8 +1562,11 @@ k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *_
 // The raw sums of the deferred K3 (kRawLines lines of six doubles per reference time) -> loss + gradient: ONE wave, lane l
 // loads line l (all loads of all reference times in flight together), DPP sums, lane 63 finishes.  This launch exists only
 // for callers that want the result ON THE DEVICE (cmax_objective); cmax_objective_raw / cmax_objective_host fold on the host.
+// flag / seq (cmax_objective_host): result and gtheta are PINNED HOST memory; after they are visible system-wide the kernel writes
+// the run counter `seq` behind them, which the host polls -- no copy engine, no hipStreamQuery.
 __global__ void __launch_bounds__(64)
-k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__restrict__ raw, double *__restrict__ result, double *__restrict__ gtheta) {
+k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__restrict__ raw, double *__restrict__ result, double *__restrict__ gtheta,
+             volatile unsigned long long *flag = nullptr, unsigned long long seq = 0) {
     const int lane = threadIdx.x;
     double v[4][6];
 #pragma unroll
@@ -1575,7 +1580,13 @@ k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__rest
 #pragma unroll
         for (int q = 0; q < 6; ++q) v[k][q] = wave_sum_lane63(v[k][q]);
     }
-    if (lane == kWave - 1) finalize_deferred(op, v, v_orig, result, gtheta);
+    if (lane == kWave - 1) {
+        finalize_deferred(op, v, v_orig, result, gtheta);
+        if (flag) {
+            __threadfence_system();
+            *flag = seq;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2426,7 +2437,8 @@ static bool deferred_applies(const cmax_handle_s *h, const cmax_objective_t *d, 
 
 static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
                             float *zero_next, double *result, void *grad, hipStream_t s, bool reuse_windows, double *raw = nullptr,
-                            bool raw_is_reset = false, bool raw_only = false, cmax::Comm *c2_comm = nullptr, bool *c2_done = nullptr) {
+                            bool raw_is_reset = false, bool raw_only = false, cmax::Comm *c2_comm = nullptr, bool *c2_done = nullptr,
+                            volatile unsigned long long *host_flag = nullptr, unsigned long long host_seq = 0) {
     int rc = 0;
     const int Hp = h->Hp, Wp = h->Wp;
     const int64_t npix = (int64_t)Hp * Wp;
@@ -2679,7 +2691,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     } else if (deferred) {
         if (!raw_only) {
             ProfScope prof(h, kProfFinish, s);
-            hipLaunchKernelGGL(k_finish_raw, dim3(1), dim3(64), 0, s, op, h->d_stat, raw, result, (double *)grad);
+            hipLaunchKernelGGL(k_finish_raw, dim3(1), dim3(64), 0, s, op, h->d_stat, raw, result, (double *)grad, host_flag, host_seq);
             CMAX_CHECK_LAUNCH();
         }
     } else if (two_dof) {
@@ -2774,7 +2786,8 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
 // vote -> [all-reduce of the images] -> finish -> [all-reduce of the gradient], all on the handle's double-buffered images
 // raw_out: non-null = stop at the raw sums of the deferred 2-DoF K3 (cmax_objective_raw; `grad` is then only a non-null marker)
 static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s,
-                          cmax::Comm *comm, double *raw_out = nullptr) {
+                          cmax::Comm *comm, double *raw_out = nullptr, volatile unsigned long long *host_flag = nullptr,
+                          unsigned long long host_seq = 0) {
     const bool dist = comm != nullptr;  // also a 1-rank communicator: the same enqueue sequence, RCCL included
     if (!raw_out && (h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
     if (raw_out && !deferred_applies(h, d, grad)) {
@@ -2816,7 +2829,7 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     }
     bool c2_done = false;  // the gradient was all-reduced in row bands behind K3 already
     rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true, raw, raw != nullptr, raw_out != nullptr,
-                          dist && grad && !raw_out ? comm : nullptr, &c2_done);
+                          dist && grad && !raw_out ? comm : nullptr, &c2_done, host_flag, host_seq);
     if (h->mu_valid) {  // K1 summed its votes and nothing consumed (and cleared) them -- an error on the way, or a path that does
         // not use them after all: the next evaluation must find clean accumulators
         (void)hipMemsetAsync(h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride, 0, (size_t)4 * kMuStride * sizeof(double), s);
@@ -2900,17 +2913,38 @@ int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *d, const void *
     if (rc) return rc;
     CMAX_REQUIRE(result_host, "objective_host: result_host");
     hipStream_t s = (hipStream_t)stream;
-    if (grad_host && !d->normalized && deferred_applies(h, d, grad_host)) {
-        // K1 -> K3 -> copy of the raw sums; the fold is 6 x 32 additions on the host, behind the copy a host caller makes anyway
-        const size_t bytes = (size_t)d->n_ref * kRawStride * sizeof(double);
+    if (grad_host && deferred_applies(h, d, grad_host)) {
+        // 2-DoF image variance: K1 -> K3 -> the one-wave finishing kernel, which writes loss and gradient STRAIGHT INTO PINNED HOST
+        // MEMORY and then a run counter behind them; the host polls that word.  No copy engine and no driver call between the
+        // last kernel and the caller (a 4 KB device-to-host copy of the raw sums + hipStreamQuery polling was 5-6 us slower per
+        // evaluation, profiles/r03_ablation.txt 10).
         rc = pinned_reserve(&h->hp_out, &h->hp_out_cap, (int64_t)4 * kRawStride);
         if (rc) return rc;
-        rc = objective_eval(h, d, motion, nullptr, (void *)h->d_raw, s, nullptr, h->d_raw);
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(h->hp_out + 16);
+        const unsigned long long seq = ++h->host_seq;
+        for (int k = 0; k < 8; ++k) h->hp_out[k] = 0.0;  // (the kernel writes the entries the descriptor uses)
+        rc = objective_eval(h, d, motion, h->hp_out, h->hp_out + 8, s, nullptr, nullptr, flag, seq);
         if (rc) return rc;
-        CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_out, h->d_raw, bytes, hipMemcpyDeviceToHost, s));
-        rc = spin_until_done(s);
-        if (rc) return rc;
-        return cmax_finalize_raw_host(h, d, h->hp_out, result_host, (double *)grad_host);
+        bool seen = false;
+        for (long spin = 0; spin < 20000000L; ++spin) {  // tens of ms at most, then ask the runtime
+            if (*flag == seq) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {
+            rc = spin_until_done(s);
+            if (rc) return rc;
+            if (*flag != seq) {
+                set_error("objective_host: the finishing kernel did not report (stream finished without its run counter)");
+                return CMAX_ESTATE;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(result_host, h->hp_out, 8 * sizeof(double));
+        std::memcpy(grad_host, h->hp_out + 8, 2 * sizeof(double));
+        return 0;
     }
     const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
     const int64_t gbytes = grad_host ? (d->model == CMAX_MODEL_2DOF ? 2 * (int64_t)sizeof(double) : gcount * (int64_t)sizeof(float)) : 0;
