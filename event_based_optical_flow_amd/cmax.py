@@ -227,7 +227,8 @@ class CMaxHandle:
     def evaluate_host(self, desc: CmaxObjective, motion, want_grad: bool = True):
         """One cmax_objective_host call: the evaluation with its results delivered to the host, the way an optimiser
         consumes them (the reference's wrapper ends in .cpu().numpy()).  Returns (result float64[8], grad ndarray or None);
-        blocks.  For the 2-DoF image-variance objective no finishing kernel runs: the raw sums ride the copy."""
+        blocks.  For the 2-DoF image-variance objective the finishing kernel writes into pinned host memory and the call polls a
+        run counter behind the results: no copy engine, no driver call on the way back."""
         m, desc = self._motion_arg(desc, motion)
         result = np.empty(8, dtype=np.float64)
         grad = None

@@ -239,9 +239,10 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const voi
 /* The same evaluation with its results delivered TO THE HOST -- what an optimiser written in C calls once per iteration
  * (the reference's TorchWrapper.get_value_and_grad ends in .cpu().numpy(), src/solver/scipy_autograd/torch_wrapper.py:46-49):
  * enqueues the evaluation and the copies on `stream` and returns when result_host[8] and grad_host (double[2] for 2DOF, else
- * fp32 [2,H,W] / [T,2,H,W]; NULL: value only) are filled.  Blocks (busy-waits on the stream).  For the 2-DoF image-variance
- * objective no finishing kernel runs at all: the gathering kernel leaves CMAX_RAW_LINES x 6 partial sums, which ride the
- * copy and are folded on the host (see cmax_objective_raw).                                       */
+ * fp32 [2,H,W] / [T,2,H,W]; NULL: value only) are filled.  Blocks (busy-waits).  For the 2-DoF image-variance objective
+ * the one-wave finishing kernel writes loss and gradient straight into pinned host memory and a run counter behind them,
+ * which this call polls: no copy engine and no driver call between the last kernel and the caller (23.7 us per sequential
+ * evaluation of 1M events, profiles/r03_ablation.txt 10).  Other objectives: cmax_objective + copies through pinned staging. */
 int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion, double *result_host,
                         void *grad_host, cmax_stream_t stream);
 
