@@ -151,6 +151,10 @@ struct cmax_handle_s {
     int seg_max = 2040;      // events per segment of the current work list (kSegMax, or 4088 for big segments)
     bool owned = false;      // the work list gives every group (empty ones included) to exactly one segment, <= kAccCells / 256 groups each
     int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
+    // What the host reads back once per batch lives in ONE allocation, in this order: d_tmm (2 doubles) | d_flags (4 ints) |
+    // d_active (ntiles ints) | d_tile_start (...): one device-to-host copy instead of four (each ~4 us of copy latency)
+    int *d_batch = nullptr;   // base of that allocation (as ints)
+    int *d_active = nullptr;  // [ntiles] source pixels that hold events, per tile (un-binned order; written by k_tile_sort)
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int4 *d_win = nullptr;        // [4][nseg] LDS windows of the last objective vote (K1 -> K3 of the same evaluation)
     // what those windows were computed for: K3 reuses them only for the same motion / model / reference times
@@ -198,6 +202,7 @@ struct cmax_handle_s {
     int4 *hp_segs = nullptr;
     int64_t hp_segs_cap = 0;
     hipEvent_t segs_copied = nullptr;  // the last upload of hp_segs has left the host buffer
+    hipEvent_t read_done = nullptr;    // the per-batch read-back has arrived (the stream may still be busy behind it)
     float2 *search_range = nullptr;           // [search_cap] (tau_min, tau_max) per patch of cmax_patch_search
     int search_cap = 0;
     int64_t bytes = 0;
@@ -1942,24 +1947,32 @@ static int pinned_reserve(T **p, int64_t *cap, int64_t count) {
     return 0;
 }
 
-static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchReadback *rb = nullptr) {
+// overlap: launched (by the caller's functor) BEHIND the read-back copies and an event, i.e. work the GPU does while the host
+// waits for that event only, cuts the segments and uploads them -- the ordering of the pixel runs by time (k_run_time_sort),
+// which moves events inside their groups and leaves the group starts alone (round 3: 0.16 -> see profiles, per 1M events)
+template <typename Overlap>
+static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchReadback *rb, Overlap overlap) {
     const int T = stride == 1 ? h->n_time_bin : 1;  // groups per tile
     const int ngroups = h->ntr * h->ntc * T;
     const int ntiles = h->ntr * h->ntc;
     const bool want_active = rb && h->n_time_bin == 0;
-    // layout of the pinned read-back: [ngroups + 1] group starts | [ntiles] active pixels | [4] flags | [2 doubles] extremes
-    const int64_t off_active = ngroups + 1, off_flags = off_active + (want_active ? ntiles : 0);
-    const int64_t off_tmm = (off_flags + 4 + 1) & ~(int64_t)1;  // 8-byte aligned
-    int rc = pinned_reserve(&h->hp_read, &h->hp_read_cap, off_tmm + 4);
+    // the pinned read-back mirrors the device allocation: [2 doubles] extremes | [4] flags | [ntiles] active pixels | [ngroups + 1] group starts
+    const int64_t off_tmm = 0, off_flags = 4, off_active = 8, off_start = 8 + ntiles;
+    (void)want_active;
+    int rc = pinned_reserve(&h->hp_read, &h->hp_read_cap, off_start + ngroups + 1);
     if (rc) return rc;
-    const int *group_start = h->hp_read;
-    CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read, h->d_tile_start, (size_t)(ngroups + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (rb) {  // what the host needs to know about the batch rides on the same synchronisation
-        if (want_active) CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read + off_active, h->cursor, (size_t)ntiles * sizeof(int), hipMemcpyDeviceToHost, s));
-        CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read + off_flags, h->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-        CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read + off_tmm, h->d_tmm, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    const int *group_start = h->hp_read + off_start;
+    CMAX_CHECK_HIP(hipMemcpyAsync(h->hp_read, h->d_batch, (size_t)(off_start + ngroups + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!h->read_done) CMAX_CHECK_HIP(hipEventCreateWithFlags(&h->read_done, hipEventDisableTiming));
+    CMAX_CHECK_HIP(hipEventRecord(h->read_done, s));
+    rc = overlap();
+    if (rc) return rc;
+    {  // busy-wait: hipEventSynchronize sleeps and wakes up tens of microseconds late
+        hipError_t e;
+        while ((e = hipEventQuery(h->read_done)) == hipErrorNotReady) {
+        }
+        CMAX_CHECK_HIP(e);
     }
-    CMAX_CHECK_HIP(hipStreamSynchronize(s));
     if (rb) {
         for (int k = 0; k < 4; ++k) rb->flags[k] = h->hp_read[off_flags + k];
         std::memcpy(rb->tmm, h->hp_read + off_tmm, 2 * sizeof(double));
@@ -2112,21 +2125,24 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
     hipLaunchKernelGGL((k_bucket_hist<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, h->counts, h->d_flags, keys);
     launch_scan(h, ntiles, s);
     hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, h->d_flags, stage);
-    hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->cursor, h->d_flags, keys);  // cursor: free again, receives the active pixels per tile
+    hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->d_active, h->d_flags, keys);
     CMAX_CHECK_LAUNCH();
     static const bool run_sort = !getenv("CMAX_NO_RUN_SORT");
-    if (T == 0 && run_sort) {
-        // pixel runs ordered by time: final SoA -> staging SoA, then the two swap roles (same capacities)
-        hipLaunchKernelGGL(k_run_time_sort, dim3(div_up(n_in, 256)), dim3(256), 0, s, fin, stage, h->counts + ntiles, h->d_flags);
-        CMAX_CHECK_LAUNCH();
-        std::swap(h->evp, h->evp_alt);
-        std::swap(h->rx, h->rx_alt);
-        std::swap(h->ry, h->ry_alt);
-        std::swap(h->tau64, h->tau64_alt);
-    }
     BatchReadback rb;
     rb.n_in = n_in;
-    return build_segments(h, T > 0 ? 1 : 256, s, &rb);
+    return build_segments(h, T > 0 ? 1 : 256, s, &rb, [&]() -> int {
+        if (T == 0 && run_sort) {
+            // pixel runs ordered by time: final SoA -> staging SoA, then the two swap roles (same capacities).  Runs on the GPU
+            // while the host cuts the segments: it needs nothing from the host and changes nothing the host reads back.
+            hipLaunchKernelGGL(k_run_time_sort, dim3(div_up(n_in, kRunSortChunk)), dim3(256), 0, s, fin, stage, h->counts + ntiles, h->d_flags);
+            CMAX_CHECK_LAUNCH();
+            std::swap(h->evp, h->evp_alt);
+            std::swap(h->rx, h->rx_alt);
+            std::swap(h->ry, h->ry_alt);
+            std::swap(h->tau64, h->tau64_alt);
+        }
+        return 0;
+    });
 }
 
 void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out) {
@@ -2183,12 +2199,21 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
     for (int k = 0; k < 5 && !rc; ++k) rc = dev_alloc(h, &h->iweb[k], npix);
     if (!rc) rc = dev_alloc(h, &h->G, 4 * npix);  // dL/dIWE of up to 4 reference times
     if (!rc) rc = dev_alloc(h, &h->Gt, npix);
-    if (!rc) rc = dev_alloc(h, &h->d_tmm, 2);
+    {
+        const int ntiles = h->ntr * h->ntc;
+        const int64_t nints = 4 /* tmm */ + 4 /* flags */ + ntiles + ((int64_t)ntiles * 256 + 1);  // tile starts: up to 255 time bins per tile
+        if (!rc) rc = dev_alloc(h, &h->d_batch, nints);
+        if (!rc) {
+            h->d_tmm = reinterpret_cast<double *>(h->d_batch);
+            h->d_flags = h->d_batch + 4;
+            h->d_active = h->d_batch + 8;
+            h->d_tile_start = h->d_batch + 8 + ntiles;
+        }
+    }
     if (!rc) rc = dev_alloc(h, &h->d_stat, kStatSlots * kStatStride);
     if (!rc) rc = dev_alloc(h, &h->counts, h->nkeys + 1);
     if (!rc) rc = dev_alloc(h, &h->cursor, h->nkeys);
     if (!rc) rc = dev_alloc(h, &h->scan_tmp, div_up(h->nkeys, kScanChunk) + 1);
-    if (!rc) rc = dev_alloc(h, &h->d_flags, 4);
     if (!rc) rc = dev_alloc(h, &h->d_raw, 4 * kRawStride);
     if (!rc) rc = dev_alloc(h, &h->d_host_result, 8);
     if (!rc) rc = dev_alloc(h, &h->d_musum, 2 * 4 * kMuStride);
@@ -2201,7 +2226,6 @@ int cmax_create(int H, int W, int ph, int pw, cmax_handle_t *out) {
         set_error("cmax_create: clearing the accumulators failed");
         rc = CMAX_ENOMEM;
     }
-    if (!rc) rc = dev_alloc(h, &h->d_tile_start, h->ntr * h->ntc * 256 + 1);  // up to 255 time bins per tile
     if (rc) {
         cmax_destroy(h);
         return rc;
@@ -2227,7 +2251,10 @@ int cmax_destroy(cmax_handle_t h) {
     for (int k = 0; k < 5; ++k) dev_free(&h->iweb[k]);
     dev_free(&h->G);
     dev_free(&h->Gt);
-    dev_free(&h->d_tmm);
+    dev_free(&h->d_batch);  // d_tmm, d_flags, d_active and d_tile_start live inside it
+    h->d_tmm = nullptr;
+    h->d_flags = nullptr;
+    h->d_tile_start = nullptr;
     dev_free(&h->d_stat);
     dev_free(&h->d_musum);
     dev_free(&h->d_raw);
@@ -2241,12 +2268,11 @@ int cmax_destroy(cmax_handle_t h) {
     if (h->hp_read) (void)hipHostFree(h->hp_read);
     if (h->hp_segs) (void)hipHostFree(h->hp_segs);
     if (h->segs_copied) (void)hipEventDestroy(h->segs_copied);
+    if (h->read_done) (void)hipEventDestroy(h->read_done);
     dev_free(&h->d_gpart);
     dev_free(&h->counts);
     dev_free(&h->cursor);
     dev_free(&h->scan_tmp);
-    dev_free(&h->d_flags);
-    dev_free(&h->d_tile_start);
     dev_free(&h->d_segs);
     dev_free(&h->d_win);
     dev_free(&h->evp);
