@@ -26,7 +26,8 @@ def draw_case(seed):
     mag = float(rng.choice([0.5, 4.0, 15.0]))
     vel = rng.uniform(-mag, mag, 2)
     ev = E.utils.generate_structured_events(n, H, W, tuple(vel), n_dots=max(3, n // 60), seed=seed, tmin=0.3, tmax=0.37)
-    if rng.random() < 0.4:  # fractional source coordinates (rectified events)
+    frac = bool(rng.random() < 0.4)
+    if frac:  # fractional source coordinates (rectified events)
         ev[:, 0] = np.minimum(ev[:, 0] + rng.uniform(0, 0.99, n), H - 1e-3)
         ev[:, 1] = np.minimum(ev[:, 1] + rng.uniform(0, 0.99, n), W - 1e-3)
     T = 0
@@ -40,7 +41,7 @@ def draw_case(seed):
         else:
             T = int(rng.choice([1, 3, 10]))
             motion = np.stack([f0 * (1.0 + 0.05 * k) for k in range(T)])
-    return dict(H=H, W=W, pad=pad, n=n, model=model, cost=cost, sigma=sigma, ev=ev, motion=motion, T=T)
+    return dict(H=H, W=W, pad=pad, n=n, model=model, cost=cost, sigma=sigma, ev=ev, motion=motion, T=T, frac=frac)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CMAX_FUZZ_SEEDS", "54"))))
@@ -67,7 +68,9 @@ def test_random_configuration_against_oracle(seed):
         frac = np.mod(w[:, :2] + 1e-6, 1.0)
         if np.isfinite(frac).all():
             n_border += int((np.minimum(frac, 1.0 - frac) < 3e-5).sum())
-    if n_border:
+    # (round 3: a 2-DoF theta crosses the ABI in fp64 here and events on a cell border are re-warped in fp64 -- the plain gate holds
+    # for integral source coordinates; fractional ones are stored as fp32 residuals, which can still flip a cell)
+    if n_border and not (c["model"] == "2d-translation" and not c["frac"]):
         tol = 2e-2
     assert abs(loss.item() - ref["loss"]) <= tol * max(abs(ref["loss"]), 1e-12), (info, loss.item(), ref["loss"])
     gmax = np.abs(ref["grad"]).max()
@@ -81,6 +84,19 @@ def test_random_configuration_against_oracle(seed):
             assert err.max() <= tol * gmax, (info, tol, err.max(), gmax)
     else:
         assert np.abs(g).max() == 0, info
+    # the same evaluation delivered to the host (cmax_objective_host; 2-DoF variance: the pinned-memory finishing kernel) and,
+    # where the objective has one, in its raw form: identical to the device-result form up to the atomics' summation order
+    desc = E.make_descriptor(c["cost"], c["model"], sigma=float(c["sigma"]), time_bin=c["T"])
+    res_h, grad_h = h.evaluate_host(desc, m.detach())
+    scale = max(abs(loss.item()), 1e-12)
+    assert abs(res_h[0] - loss.item()) <= 2e-6 * scale, (info, res_h[0], loss.item())
+    if gmax > 0:
+        assert np.abs(grad_h - g).max() <= 2e-5 * np.abs(g).max() + 1e-30, info
+    if h.has_raw(desc):
+        call, raw, finalize = h.prepare_raw(desc, m.detach())
+        call()
+        res_r, grad_r = finalize()
+        assert abs(res_r[0] - loss.item()) <= 2e-6 * scale and np.abs(grad_r - g).max() <= 2e-5 * np.abs(g).max() + 1e-30, info
 
 
 # ---- the optimiser's objective (native one-call plan and autograd-chained path) ----------------------------------
