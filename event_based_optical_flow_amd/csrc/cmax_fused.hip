@@ -1265,6 +1265,15 @@ struct TanParams {
     int64_t bs;           // element stride between the per-reference-time images
 };
 
+// deterministic mode of the second-order gather (k_grad_hvp): all null / zero in the default mode
+struct HvpDet {
+    long long *g64;        // 2-DoF: per-segment partial sums [n_ref][nseg][2]; flow models: fixed-point accumulators of the product
+    const unsigned *imax;  // bits of max |G_k| at [k], of max |G'_k| at [4 + k]
+    double *inv_scale;     // [4] 1 / scale of reference time k (2-DoF) or of the whole launch ([0])
+    long long n_events;
+    int n_ref;
+};
+
 // (da, db) of cached event slot: d(x', y')/d(motion) . u
 template <int MODEL>
 __device__ __forceinline__ void tangent_delta(const WarpParams &wp, const TanParams &tp, float dt, unsigned key, float u0, float u1,
@@ -1390,13 +1399,14 @@ struct FixedArgs {
     long long *src[5];
     float *dst[5];
     double inv_fix;  // 1 / the vote fixed point of the kernels that filled src: 2^-20, big segments 2^-19
+    double inv_fixk[5];  // != 0: per-image scale instead (tangent votes: one fixed point per reference time)
 };
 __global__ void __launch_bounds__(256) k_fixed_to_image(FixedArgs fa, int64_t npix) {
     long long *__restrict__ src = fa.src[blockIdx.y];
     float *__restrict__ dst = fa.dst[blockIdx.y];
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
         const long long v = src[p];
-        dst[p] = (float)((double)v * fa.inv_fix);  // one rounding, of the exact sum
+        dst[p] = (float)((double)v * (fa.inv_fixk[blockIdx.y] != 0.0 ? fa.inv_fixk[blockIdx.y] : fa.inv_fix));  // one rounding, of the exact sum
         if (v != 0) src[p] = 0;
     }
 }
@@ -3010,7 +3020,7 @@ int cmax_set_deterministic(cmax_handle_t h, int enable) {
             }
         }
         if (!h->d_imax) {
-            int rc = dev_alloc(h, &h->d_imax, kStatSlots);
+            int rc = dev_alloc(h, &h->d_imax, 8);  // [0..4]: images of the objective; HVP: [0..3] max |G_k|, [4..7] max |G'_k|
             if (rc) return rc;
         }
         if (!h->d_det_inv_scale) {
@@ -3090,24 +3100,25 @@ namespace cmax {
 
 // tangent votes of every reference time (blockIdx.y) into draw + k * tp.bs (zeroed by the caller)
 template <int MODEL>
-static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, float *draw, hipStream_t s) {
+static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, float *draw, hipStream_t s,
+                            long long *draw64 = nullptr) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     if (h->big) {
-        if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
-        else hipLaunchKernelGGL((b512::k_vote_tan<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
-    } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
-    else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan);
+        if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
+        else hipLaunchKernelGGL((b512::k_vote_tan<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
+    } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
+    else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
 }
 
 template <int MODEL>
 static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const TanParams &tp, int n_ref, const float *G,
-                            const float *Gp, double *gpart, float *hflow, hipStream_t s) {
+                            const float *Gp, double *gpart, float *hflow, hipStream_t s, const HvpDet &det) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
     if (h->big) {
-        if (h->has_frac) hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
-        else hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
-    } else if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
-    else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow);
+        if (h->has_frac) hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
+        else hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
+    } else if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
+    else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
 }
 
 }  // namespace cmax
@@ -3202,12 +3213,27 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
     CMAX_CHECK_LAUNCH();
     // T1: tangent images and their blur
     CMAX_CHECK_HIP(hipMemsetAsync(dI, 0, (size_t)nr * npix * sizeof(float), s));
+    // deterministic mode (round 3): the tangent votes go to the integer images (all zero between uses) and are rounded to fp32
+    // once; the second-order gather below accumulates integers -- the product is then bit-identical from run to run like the
+    // loss and the gradient
+    const bool det = h->deterministic;
+    long long *dI64 = det ? h->img64 : nullptr;
     switch (d->model) {
-        case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, dI, s); break;
-        case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, dI, s); break;
-        default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, dI, s); break;
+        case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, dI, s, dI64); break;
+        case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, dI, s, dI64); break;
+        default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, dI, s, dI64); break;
     }
     CMAX_CHECK_LAUNCH();
+    if (det) {
+        FixedArgs fa = {};
+        for (int k = 0; k < nr; ++k) {
+            fa.src[k] = h->img64 + (int64_t)k * npix;
+            fa.dst[k] = dI + k * npix;
+            fa.inv_fixk[k] = 1.0 / (double)tp.fixk[k];
+        }
+        hipLaunchKernelGGL(k_fixed_to_image, dim3(stream_grid(npix, 256), nr), dim3(256), 0, s, fa, npix);
+        CMAX_CHECK_LAUNCH();
+    }
     if (d->sigma > 0) {
         hipLaunchKernelGGL(k_blur3<float>, igrid, dim3(256), 0, s, dI, Hp, Wp, (float)k0, (float)k1, dIb, bs);
         dimg = dIb;
@@ -3229,13 +3255,47 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
     }
     CMAX_CHECK_LAUNCH();
     // T3
+    HvpDet hd = {};
+    if (det) {
+        // the bounds the fixed-point scale is derived from: max |G_k| and max |G'_k| (integer maxima: order-free)
+        CMAX_CHECK_HIP(hipMemsetAsync(h->d_imax, 0, 8 * sizeof(unsigned), s));
+        ImgArgs ig = {}, ip = {};
+        for (int k = 0; k < nr; ++k) {
+            ig.in[k] = h->G + k * npix;
+            ip.in[k] = Gp + k * npix;
+        }
+        const dim3 mgrid(std::min(stream_grid(npix, 1024), 256), nr);
+        hipLaunchKernelGGL(k_image_absmax, mgrid, dim3(256), 0, s, ig, npix, 0, h->d_imax);
+        hipLaunchKernelGGL(k_image_absmax, mgrid, dim3(256), 0, s, ip, npix, 4, h->d_imax);
+        CMAX_CHECK_LAUNCH();
+        if (!two_dof && gcount > h->g64_cap) {
+            CMAX_CHECK_HIP(hipStreamSynchronize(s));
+            dev_free(&h->g64);
+            h->g64_cap = 0;
+            rc = dev_alloc(h, &h->g64, gcount);
+            if (rc) return rc;
+            h->g64_cap = gcount;
+            CMAX_CHECK_HIP(hipMemsetAsync(h->g64, 0, (size_t)gcount * sizeof(long long), s));
+        }
+        hd.g64 = two_dof ? reinterpret_cast<long long *>(h->d_gpart) : h->g64;  // (d_gpart: [4][nseg][2] doubles = as many 64-bit integers)
+        hd.imax = h->d_imax;
+        hd.inv_scale = h->d_det_inv_scale;
+        hd.n_events = h->n;
+        hd.n_ref = nr;
+    }
     switch (d->model) {
-        case CMAX_MODEL_2DOF: launch_grad_hvp<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, h->G, Gp, h->d_gpart, nullptr, s); break;
-        case CMAX_MODEL_DENSE: launch_grad_hvp<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, h->G, Gp, nullptr, (float *)hv, s); break;
-        default: launch_grad_hvp<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, h->G, Gp, nullptr, (float *)hv, s); break;
+        case CMAX_MODEL_2DOF: launch_grad_hvp<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, h->G, Gp, h->d_gpart, nullptr, s, hd); break;
+        case CMAX_MODEL_DENSE: launch_grad_hvp<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, h->G, Gp, nullptr, (float *)hv, s, hd); break;
+        default: launch_grad_hvp<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, h->G, Gp, nullptr, (float *)hv, s, hd); break;
     }
     CMAX_CHECK_LAUNCH();
-    if (two_dof) {
+    if (det) {
+        if (two_dof)
+            hipLaunchKernelGGL(k_finish_det, dim3(1), dim3(256), 0, s, reinterpret_cast<long long *>(h->d_gpart), h->nseg, nr, h->d_det_inv_scale, (double *)hv);
+        else
+            hipLaunchKernelGGL(k_fixed_to_grad, dim3(stream_grid(gcount, 256)), dim3(256), 0, s, h->g64, (float *)hv, gcount, h->d_det_inv_scale);
+        CMAX_CHECK_LAUNCH();
+    } else if (two_dof) {
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)hv);
         CMAX_CHECK_LAUNCH();
     }

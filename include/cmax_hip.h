@@ -342,7 +342,7 @@ int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, cons
                         double *result, void *grad, cmax_stream_t stream);
 
 /* Deterministic mode ("race detection"): bit-identical IWE, loss and gradient from run
- * to run for cmax_iwe / cmax_objective / cmax_objective_vote + _finish.  By default the vote flush, the flow
+ * to run for cmax_iwe / cmax_objective / cmax_objective_vote + _finish / cmax_objective_hvp.  By default the vote flush, the flow
  * gradient and the contrast statistics use floating-point atomics, whose order -- like the order of events inside
  * a sorted group -- varies between runs, so results differ in their last bits (~1e-7 relative).  With enable != 0
  * everything that depends on such an order is accumulated in INTEGERS: votes as 2^-20 fixed point in a 64-bit image
@@ -350,8 +350,9 @@ int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, cons
  * per workgroup and with 64-bit global atomics, statistics with one workgroup per accumulator and the unfused image
  * kernels.  Same arithmetic per event, same parity (1e-4 of the reference); slower: no fused image kernels, one pair
  * of global atomics per event for the flow gradient (dense 5M events: ~10x an evaluation), 40 B per pixel more HBM.
- * Not covered: cmax_objective_hvp, the patch plan's own kernels; across ranks (cmax_objective_dist) the result is as
- * repeatable as RCCL's reduction order.                                                                          */
+ * cmax_objective_hvp is covered as well (round 3: integer tangent-vote images, integer accumulation of the second-order gather).
+ * Not covered: the patch plan's own kernels (interpolation adjoint, voxel chain); across ranks (cmax_objective_dist) the result
+ * is as repeatable as RCCL's reduction order.                                                                      */
 int cmax_set_deterministic(cmax_handle_t h, int enable);
 int cmax_get_deterministic(cmax_handle_t h, int *enabled);
 

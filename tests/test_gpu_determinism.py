@@ -104,3 +104,38 @@ def test_switching_modes_on_one_handle():
         assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL, det
     iwe = h.iwe(theta, "2d-translation").cpu().numpy()  # cmax_iwe in deterministic mode
     assert rel_max(iwe, ref["iwes"]["iwe"]) <= TOL
+
+
+@pytest.mark.parametrize("model,cost,sigma,Tn", CASES, ids=[f"{c[0]}-{c[1]}-s{int(c[2])}" for c in CASES])
+def test_hvp_bit_repeatable(model, cost, sigma, Tn):
+    """Round 3: cmax_objective_hvp in deterministic mode -- integer tangent-vote images, one-writer tangent statistics, integer
+    accumulation of the second-order gather.  Three FRESH handles (the sort reorders events between them), two products each:
+    identical bytes; equal to the default mode's product to fp32 accumulation noise; symmetric against a second tangent."""
+    size, n = (120, 160), 150_000
+    if model == "2d-translation":
+        ev = E.utils.generate_structured_events(n, size[0], size[1], (13.0, -8.0), n_dots=600, seed=37)
+    else:
+        ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=37)
+    motion = _motion(model, size, Tn)
+    desc = E.make_descriptor(cost, model, sigma=sigma, time_bin=Tn)
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(np.asarray(motion).shape)
+    v = rng.standard_normal(np.asarray(motion).shape)
+
+    def products(deterministic):
+        h = E.CMaxHandle(size)
+        h.set_deterministic(deterministic)
+        h.set_events(ev, time_bin=Tn)
+        outs = [h.hvp(desc, motion, u).cpu().numpy() for _ in range(2)]
+        return outs, h.hvp(desc, motion, v).cpu().numpy()
+
+    runs = [products(True) for _ in range(3)]
+    first = runs[0][0][0].tobytes()
+    for outs, _ in runs:
+        for o in outs:
+            assert o.tobytes() == first, "deterministic mode produced different bits in the Hessian-vector product"
+    Hu, Hv = runs[0][0][0].astype(np.float64), runs[0][1].astype(np.float64)
+    Hu_default = products(False)[0][0]
+    assert rel_max(Hu_default, Hu) <= 2e-4  # fp32 atomics / another summation order on the default side
+    lhs, rhs = float((v * Hu).sum()), float((u * Hv).sum())
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1e-300), (lhs, rhs)  # <v, H u> = <u, H v>
