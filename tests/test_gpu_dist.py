@@ -81,6 +81,10 @@ def test_objective_dist_world1_rccl(world1_nccl, model, cost, sigma, Tn):
     h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
     res, grad = h.evaluate(desc, motion)
     assert h.comm_info() == (1, 0, 0)
+    ok, rccl_path = h.comm_available()  # a local call: binds RCCL and says where it came from
+    assert ok and os.path.basename(rccl_path).startswith("librccl"), rccl_path
+    # the copy the process already holds (torch's) must be the one bound: a second RCCL would bring its own topology and IPC state
+    assert os.path.realpath(rccl_path) == os.path.realpath(os.path.join(os.path.dirname(torch.__file__), "lib", os.path.basename(rccl_path))), rccl_path
     h.comm_init(force_rccl=True)
     nranks, rank, version = h.comm_info()
     assert (nranks, rank) == (1, 0) and version > 0, "RCCL was not bound"
