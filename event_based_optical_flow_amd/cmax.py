@@ -259,8 +259,8 @@ class CMaxHandle:
         return call, result, grad
 
     def has_raw(self, desc: CmaxObjective) -> bool:
-        """Whether `desc` on the current batch has a raw form (cmax_objective_has_raw): 2-DoF, image variance, sigma 0, not
-        normalised, default (non-deterministic) mode, a non-empty batch."""
+        """Whether `desc` on the current batch has a raw form (cmax_objective_has_raw): every 2-DoF objective in the default
+        (non-deterministic) mode on a non-empty batch, except a normalised plain variance."""
         return bool(self._lib.cmax_objective_has_raw(self._h, ctypes.byref(desc)))
 
     def prepare_raw(self, desc: CmaxObjective, motion):
@@ -270,7 +270,7 @@ class CMaxHandle:
         hundred additions."""
         m, desc = self._motion_arg(desc, motion)
         if not self.has_raw(desc):
-            raise _lib.CmaxError(-1, "this objective has no raw form (2-DoF, image variance, sigma 0, not normalised)")
+            raise _lib.CmaxError(-1, "this objective has no raw form (2-DoF, default mode, non-empty batch; not a normalised plain variance)")
         raw = torch.empty((desc.n_ref, _lib.RAW_DOUBLES), dtype=torch.float64, device=self.device)
         host = torch.empty((desc.n_ref, _lib.RAW_DOUBLES), dtype=torch.float64).pin_memory()
         fn, fin = self._lib.cmax_objective_raw, self._lib.cmax_finalize_raw_host

@@ -93,6 +93,7 @@ struct RefArgs {
     float d[4];       // reference time as a fraction of the batch period
     float *img[4];    // K1: vote image to fill; K3: image to gather from (dL/dIWE or the IWE itself)
     double *stat[4];  // K1: statistics accumulators to reset (or null)
+    double *raw_zero; // K1: [n_ref][kRawStride] gradient-sum lines of the 2-DoF K3 of the same evaluation to reset (or null)
     float *zero[4];   // K3, deferred statistics: vote image of the NEXT evaluation to clear (or null)
     int k0;           // index of the first reference time of this launch (statistics slot, partial-sum offset)
     int4 *win;        // [n_ref][nseg] LDS windows: written by K1, read by K3 of the same evaluation (or null)
@@ -1467,6 +1468,33 @@ __global__ void __launch_bounds__(256) k_finish_det(long long *__restrict__ gpar
     }
 }
 
+// 2-DoF objectives that keep statistics (everything but the deferred plain variance): K3 left sum dt g in doubles 0, 1 of kRawLines
+// lines per reference time; gradient = their sum over lines and reference times.  One wave.  result_src -> result_dst / flag / seq:
+// cmax_objective_host -- copy the result K3's first workgroup wrote to the device into pinned host memory beside the gradient and
+// publish a run counter behind both.
+__global__ void __launch_bounds__(64)
+k_finish_lines(const double *__restrict__ raw, int n_ref, double *__restrict__ gtheta, const double *__restrict__ result_src,
+               double *__restrict__ result_dst, volatile unsigned long long *flag, unsigned long long seq) {
+    const int lane = threadIdx.x;
+    double g0 = 0.0, g1 = 0.0;
+    for (int k = 0; k < n_ref; ++k)
+        if (lane < kRawLines) {
+            g0 += raw[(int64_t)k * kRawStride + lane * kSubStride];
+            g1 += raw[(int64_t)k * kRawStride + lane * kSubStride + 1];
+        }
+    g0 = wave_sum_lane63(g0);
+    g1 = wave_sum_lane63(g1);
+    if (result_dst && lane < 8) result_dst[lane] = result_src[lane];
+    if (lane == kWave - 1) {
+        gtheta[0] = g0;
+        gtheta[1] = g1;
+    }
+    if (flag) {
+        __threadfence_system();
+        if (lane == kWave - 1) *flag = seq;
+    }
+}
+
 }  // namespace cmax
 
 // the event kernels, once per workgroup size
@@ -1794,10 +1822,11 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
 // mu_taps: non-null = also accumulate sum_p I[p] B[p] for the blurred variance (taps k0, k1 of the blur, omit_boundary in [2])
 static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, int n_ref, const int *ref_mode, const double *ref_frac,
                        int normalize, float *const *imgs, unsigned zero_mask, int stat_slot0, hipStream_t s, bool publish_windows = false,
-                       const float *mu_taps = nullptr, int motion_f64 = 0, double *raw_reset = nullptr) {
+                       const float *mu_taps = nullptr, int motion_f64 = 0, double *raw_reset = nullptr, double *raw_lines = nullptr) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     RefArgs ra = {};
     ra.k0 = 0;
+    ra.raw_zero = raw_lines;  // (the deferred objective resets its sums through ra.stat instead: raw_reset)
     if (publish_windows && h->n > 0) {  // K3 of the same evaluation re-uses the LDS windows (see objective_finish)
         ra.win = h->d_win;
         h->win_motion = motion;
@@ -2423,7 +2452,7 @@ static bool owned_groups_apply(const cmax_handle_s *h, const cmax_objective_t *d
 // votes of every reference time (+ the un-warped image when needed) into images[0 .. n_images);
 // zero_mask bit k: images[k] is already zero (the handle's double-buffered images)
 static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
-                          int *n_images_out, hipStream_t s, bool want_mu = false, double *raw_reset = nullptr) {
+                          int *n_images_out, hipStream_t s, bool want_mu = false, double *raw_reset = nullptr, double *raw_lines = nullptr) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
     h->mu_valid = false;
     {
@@ -2437,7 +2466,7 @@ static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const floa
             mu_taps[1] = (float)k1;
         }
         int rc = vote_images(h, d->model, motion, d->T, d->n_ref, d->ref_mode, d->ref_frac, d->normalize_t, imgs, zero_mask, 0, s, true,
-                             want_mu ? mu_taps : nullptr, d->motion_dtype == CMAX_F64, raw_reset);
+                             want_mu ? mu_taps : nullptr, d->motion_dtype == CMAX_F64, raw_reset, raw_lines);
         if (rc) return rc;
     }
     int n_images = d->n_ref;
@@ -2469,6 +2498,11 @@ int cmax_objective_vote(cmax_handle_t h, const cmax_objective_t *d, const void *
 static bool deferred_applies(const cmax_handle_s *h, const cmax_objective_t *d, const void *grad) {
     return !h->deterministic && grad && d->model == CMAX_MODEL_2DOF && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) && h->n > 0 &&
            (int64_t)h->Hp * h->Wp <= (int64_t)h->nseg * 8192;
+}
+
+// every 2-DoF objective of the default mode leaves its gradient as sums in kRawLines lines (deferred: six sums, loss included)
+static bool two_dof_lines(const cmax_handle_s *h, const cmax_objective_t *d, const void *grad) {
+    return !h->deterministic && grad && d->model == CMAX_MODEL_2DOF && h->n > 0;
 }
 
 static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
@@ -2511,12 +2545,13 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // every sum in a fixed order) and the integer-accumulating K3
     const bool det = h->deterministic;
     const bool deferred = deferred_applies(h, d, grad);
-    if (raw_only && !deferred) {
-        set_error("objective_raw: this objective has no raw form (2-DoF, image variance, sigma 0, a non-empty batch, not deterministic)");
+    const bool lines = two_dof_lines(h, d, grad);  // (includes the deferred case)
+    if (raw_only && !lines) {
+        set_error("objective_raw: this objective has no raw form (2-DoF, a non-empty batch, not deterministic)");
         return CMAX_EINVAL;
     }
-    if (deferred && !raw) raw = h->d_raw;
-    if (deferred && !raw_is_reset) CMAX_CHECK_HIP(hipMemsetAsync(raw, 0, (size_t)d->n_ref * kRawStride * sizeof(double), s));
+    if (lines && !raw) raw = h->d_raw;
+    if (lines && !raw_is_reset) CMAX_CHECK_HIP(hipMemsetAsync(raw, 0, (size_t)d->n_ref * kRawStride * sizeof(double), s));
     // gradient magnitude with a gradient: K2 and K2b (and the blurs) are one kernel: statistics + G image without its chain factor
     const bool fused_gm = !det && grad && d->cost == CMAX_COST_GRADMAG && h->n > 0;
     const bool blur_var = !det && d->cost == CMAX_COST_VARIANCE && d->sigma > 0;  // blur + statistics in one kernel
@@ -2675,7 +2710,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
     const EvView ev = ev_view(h);
     const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
-    double *res = deferred ? nullptr : result;  // the last workgroup of the last reference time writes the loss
+    // the first workgroup writes the loss (deferred: the finishing step does).  Raw form of an objective with statistics: into doubles
+    // 8..15 of the first line of the raw buffer (the sums use doubles 0, 1 of every line)
+    double *res = deferred ? nullptr : ((raw_only && lines) ? raw + 8 : result);
     // C2 in row bands (cmax_comm_set_c2_bands): dense objective on an owned work list under a communicator.  The owned K3 STORES
     // every gradient element of its segments' tiles, so after the launch that covers tile rows [a, b) the pixel rows [16 a, 16 b)
     // of both channels are final on this rank: they are all-reduced on the handle's second stream while the caller's stream
@@ -2712,7 +2749,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         return 0;
     }
     switch (d->model) {
-        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, deferred ? raw : h->d_gpart, nullptr, res, false, s); break;
+        case CMAX_MODEL_2DOF: launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, fold, op, lines ? raw : h->d_gpart, nullptr, res, false, s); break;
         case CMAX_MODEL_DENSE: launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
         default: launch_grad<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, fold, op, nullptr, (float *)grad, res, owned, s); break;
     }
@@ -2731,9 +2768,13 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             CMAX_CHECK_LAUNCH();
         }
     } else if (two_dof) {
-        ProfScope prof(h, kProfFinish, s);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)grad);
-        CMAX_CHECK_LAUNCH();
+        if (!raw_only) {
+            ProfScope prof(h, kProfFinish, s);
+            // (host_flag: cmax_objective_host -- `result` and `grad` are pinned host memory; K3's first workgroup wrote the loss there)
+            hipLaunchKernelGGL(k_finish_lines, dim3(1), dim3(64), 0, s, raw, d->n_ref, (double *)grad, (const double *)nullptr, (double *)nullptr,
+                               host_flag, host_seq);
+            CMAX_CHECK_LAUNCH();
+        }
     }
     return 0;
 }
@@ -2826,8 +2867,8 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
                           unsigned long long host_seq = 0) {
     const bool dist = comm != nullptr;  // also a 1-rank communicator: the same enqueue sequence, RCCL included
     if (!raw_out && (h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
-    if (raw_out && !deferred_applies(h, d, grad)) {
-        set_error("objective_raw: this objective has no raw form (2-DoF, image variance, sigma 0, a non-empty batch, not deterministic)");
+    if (raw_out && !two_dof_lines(h, d, grad)) {
+        set_error("objective_raw: this objective has no raw form (2-DoF, a non-empty batch, not deterministic)");
         return CMAX_EINVAL;
     }
     const int64_t gcount = d->model == CMAX_MODEL_2DOF ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
@@ -2852,9 +2893,12 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     static const bool no_stats_inside = getenv("CMAX_NO_STATS_INSIDE") != nullptr;  // tuning: k_stats as a launch of its own
     const bool var_from_votes = !dist && !no_stats_inside && owned_groups_apply(h, d, grad) && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) &&
                                 !d->normalized && h->Hp >= 4 && h->Wp >= 4;
-    // deferred 2-DoF objective: K1 clears the raw sums its K3 adds into
-    double *raw = deferred_applies(h, d, grad) ? (raw_out ? raw_out : h->d_raw) : nullptr;
-    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes || var_from_votes, raw);
+    // 2-DoF objectives: K1 clears the raw sums its K3 adds into -- through its statistics slot when the objective keeps none
+    // (deferred), through RefArgs::raw_zero otherwise
+    double *raw = two_dof_lines(h, d, grad) ? (raw_out ? raw_out : h->d_raw) : nullptr;
+    const bool raw_deferred = raw && deferred_applies(h, d, grad);
+    int rc = objective_vote(h, d, motion, cur, h->zero_mask[h->cur_buf], &n_images, s, blurvar_from_votes || var_from_votes,
+                            raw_deferred ? raw : nullptr, raw_deferred ? nullptr : raw);
     if (rc) return rc;
     const unsigned used = (1u << n_images) - 1u;
     h->zero_mask[h->cur_buf] &= ~used;  // now holds votes
@@ -2902,7 +2946,9 @@ int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *d, const void *
 
 int cmax_objective_has_raw(cmax_handle_t h, const cmax_objective_t *d) {
     if (!h || !d) return 0;
-    return deferred_applies(h, d, (const void *)h) && !d->normalized ? 1 : 0;
+    if (!two_dof_lines(h, d, (const void *)h)) return 0;
+    // (a NORMALISED plain variance runs the deferred K3, whose fold needs the un-warped image's statistics from the device)
+    return deferred_applies(h, d, (const void *)h) && d->normalized ? 0 : 1;
 }
 
 int cmax_objective_raw(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, double *raw, cmax_stream_t stream) {
@@ -2910,13 +2956,31 @@ int cmax_objective_raw(cmax_handle_t h, const cmax_objective_t *d, const void *m
     int rc = check_objective_args(h, d, motion);
     if (rc) return rc;
     CMAX_REQUIRE(raw, "objective_raw: raw");
-    CMAX_REQUIRE(!d->normalized, "objective_raw: normalised costs need the un-warped image's statistics: use cmax_objective");
+    CMAX_REQUIRE(cmax_objective_has_raw(h, d), "objective_raw: this objective has no raw form (see cmax_objective_has_raw)");
     return objective_eval(h, d, motion, nullptr, (void *)raw, (hipStream_t)stream, nullptr, raw);
 }
 
 int cmax_finalize_raw_host(cmax_handle_t h, const cmax_objective_t *d, const double *raw_host, double *result_host, double *grad_host) {
     CMAX_REQUIRE(h && d && raw_host && result_host, "finalize_raw_host: null pointer");
-    CMAX_REQUIRE(d->n_ref >= 1 && d->n_ref <= 4 && !d->normalized, "finalize_raw_host: descriptor");
+    CMAX_REQUIRE(d->n_ref >= 1 && d->n_ref <= 4 && d->model == CMAX_MODEL_2DOF, "finalize_raw_host: descriptor");
+    for (int k = 0; k < 8; ++k) result_host[k] = 0.0;
+    if (!deferred_applies(h, d, (const void *)h)) {
+        // objectives that keep statistics: K3's first workgroup wrote result[8] into doubles 8..15 of the first line, every
+        // workgroup added sum dt g into doubles 0, 1 of a line
+        for (int k = 0; k < 8; ++k) result_host[k] = raw_host[8 + k];
+        if (grad_host) {
+            double g0 = 0.0, g1 = 0.0;
+            for (int k = 0; k < d->n_ref; ++k)
+                for (int l = 0; l < kRawLines; ++l) {
+                    g0 += raw_host[(int64_t)k * kRawStride + l * kSubStride];
+                    g1 += raw_host[(int64_t)k * kRawStride + l * kSubStride + 1];
+                }
+            grad_host[0] = g0;
+            grad_host[1] = g1;
+        }
+        return 0;
+    }
+    CMAX_REQUIRE(!d->normalized, "finalize_raw_host: a normalised plain variance needs the un-warped image's statistics (use cmax_objective_host)");
     const ObjParams op = obj_params(h, d);
     double S[4][6];
     for (int k = 0; k < d->n_ref; ++k)
@@ -2925,7 +2989,6 @@ int cmax_finalize_raw_host(cmax_handle_t h, const cmax_objective_t *d, const dou
             for (int l = 0; l < kRawLines; ++l) a += raw_host[(int64_t)k * kRawStride + l * kSubStride + q];
             S[k][q] = a;
         }
-    for (int k = 0; k < 8; ++k) result_host[k] = 0.0;
     finalize_deferred(op, S, 0.0, result_host, grad_host);
     return 0;
 }
@@ -2949,8 +3012,8 @@ int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *d, const void *
     if (rc) return rc;
     CMAX_REQUIRE(result_host, "objective_host: result_host");
     hipStream_t s = (hipStream_t)stream;
-    if (grad_host && deferred_applies(h, d, grad_host)) {
-        // 2-DoF image variance: K1 -> K3 -> the one-wave finishing kernel, which writes loss and gradient STRAIGHT INTO PINNED HOST
+    if (grad_host && two_dof_lines(h, d, grad_host)) {
+        // 2-DoF objectives: K1 [-> image kernel] -> K3 -> the one-wave finishing kernel, which writes (loss and) gradient STRAIGHT INTO PINNED HOST
         // MEMORY and then a run counter behind them; the host polls that word.  No copy engine and no driver call between the
         // last kernel and the caller (a 4 KB device-to-host copy of the raw sums + hipStreamQuery polling was 5-6 us slower per
         // evaluation, profiles/r03_ablation.txt 10).

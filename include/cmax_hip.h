@@ -246,15 +246,18 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const voi
 int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion, double *result_host,
                         void *grad_host, cmax_stream_t stream);
 
-/* Raw form of the 2-DoF image-variance objective (sigma 0, not normalised, default mode, non-empty batch:
- * cmax_objective_has_raw says whether a descriptor qualifies).  cmax_objective spends a third of such an evaluation in a
- * one-workgroup kernel that only adds up what the gathering kernel left and divides a few numbers; here that kernel is not
- * launched.  `raw` (device, CMAX_RAW_DOUBLES doubles per reference time, cleared by the library inside the evaluation)
- * receives CMAX_RAW_LINES partial sums -- one 128-byte line each, doubles 0..5 of a line = (S1x, S1y, S2x, S2y, sum I,
- * sum I^2) with S1 = sum_e dt * bilinear-difference(1_Omega IWE), S2 = the same of 1_Omega -- added with fp64 atomics by the
- * gathering workgroups.  The CONSUMER finishes: copy the buffer to the host whenever it needs the numbers and call
- * cmax_finalize_raw_host (pure host arithmetic: sums the lines, then loss = -/+ var, dL/dtheta = c (S1 - mu S2)).
- * Asynchronous like cmax_objective.                                                              */
+/* Raw form of the 2-DoF objectives (default mode, non-empty batch; cmax_objective_has_raw says whether a descriptor on the
+ * current batch qualifies -- everything 2-DoF except a NORMALISED plain variance, whose fold needs device-side statistics).
+ * cmax_objective ends such an evaluation with a one-wave kernel that only adds up what the gathering kernel left and divides a
+ * few numbers -- a third of the headline evaluation, as a launch; here that kernel is not launched.  `raw` (device,
+ * CMAX_RAW_DOUBLES doubles per reference time, cleared by the library inside the evaluation) receives CMAX_RAW_LINES partial
+ * sums, one 128-byte line each, added with fp64 atomics by the gathering workgroups:
+ *   image variance, sigma 0 ("deferred statistics": no image kernel runs at all): doubles 0..5 of a line =
+ *     (S1x, S1y, S2x, S2y, sum I, sum I^2), S1 = sum_e dt * bilinear-difference(1_Omega IWE), S2 = the same of 1_Omega;
+ *   every other objective: doubles 0, 1 = sum_e dt * dL/d(x', y') (chain factors applied), and doubles 8..15 of the FIRST
+ *     line = result[8] as cmax_objective would deliver it (written by the gathering kernel's first workgroup).
+ * The CONSUMER finishes: copy the buffer to the host whenever it needs the numbers and call cmax_finalize_raw_host (pure host
+ * arithmetic: sums the lines; deferred form: loss = -/+ var, dL/dtheta = c (S1 - mu S2)).  Asynchronous like cmax_objective. */
 #define CMAX_RAW_LINES 32
 #define CMAX_RAW_DOUBLES (CMAX_RAW_LINES * 16)
 int cmax_objective_has_raw(cmax_handle_t h, const cmax_objective_t *desc_host);

@@ -517,6 +517,35 @@ def test_two_dof_raw_and_host_forms(n_ref_cost, pad, frac):
             h.prepare_raw(desc, theta)
 
 
+@pytest.mark.parametrize("cost,sigma", [("gradient_magnitude", 0.0), ("image_variance", 1.0), ("multi_focal_normalized_gradient_magnitude", 1.0),
+                                        ("normalized_image_variance", 1.0)])
+def test_two_dof_raw_form_of_objectives_with_statistics(cost, sigma):
+    """Every 2-DoF objective of the default mode has a raw form: K3 adds sum dt g into 32 lines and its first workgroup writes the
+    result into the spare doubles of the first line; the consumer folds (no k_finish launch).  Device, host and raw forms agree with
+    each other and with the oracle; repeated, and interleaved on one handle."""
+    size, n = (120, 160), 200_000
+    ev = E.utils.generate_structured_events(n, size[0], size[1], (9.0, -6.0), n_dots=300, seed=22)
+    theta = np.array([8.0, -5.0])
+    h = E.CMaxHandle(size).set_events(ev)
+    desc = E.make_descriptor(cost, "2d-translation", sigma=sigma)
+    ref = orc.objective(ev, theta, "2d-translation", size, cost=cost, sigma=int(sigma))
+    assert h.has_raw(desc)
+    call, raw, finalize = h.prepare_raw(desc, theta)
+    for rep in range(3):
+        call()
+        res_r, grad_r = finalize()
+        assert abs(res_r[0] - ref["loss"]) <= TOL * abs(ref["loss"]), (rep, res_r[0], ref["loss"])
+        assert rel_max(grad_r, ref["grad"]) <= TOL
+    res_d, grad_d = h.evaluate(desc, theta)
+    res_h, grad_h = h.evaluate_host(desc, theta)
+    call()
+    res_r, grad_r = finalize()
+    for res, grad in ((res_d.cpu().numpy(), grad_d.cpu().numpy()), (res_h, grad_h)):
+        assert abs(res[0] - res_r[0]) <= 1e-6 * abs(res_r[0]) and rel_max(grad, grad_r) <= 1e-5
+    for k in range(1, 1 + desc.n_ref):  # the per-reference-time contrasts ride along
+        assert abs(res_r[k] - res_d[k].item()) <= 1e-6 * abs(res_r[k])
+
+
 @pytest.mark.parametrize("model,cost,sigma", [("dense-flow", "gradient_magnitude", 1.0), ("dense-flow-voxel", "image_variance", 0.0),
                                                ("2d-translation", "gradient_magnitude", 0.0)])
 def test_objective_host_other_models(model, cost, sigma):
@@ -537,8 +566,11 @@ def test_objective_host_other_models(model, cost, sigma):
         assert abs(res[0] - ref["loss"]) <= TOL * abs(ref["loss"])
         if want_grad:
             assert rel_max(grad, ref["grad"]) <= TOL
-    with pytest.raises(E._lib.CmaxError):
-        h.prepare_raw(desc, motion)
+    if model == "2d-translation":
+        assert h.has_raw(desc)
+    else:
+        with pytest.raises(E._lib.CmaxError):
+            h.prepare_raw(desc, motion)
 
 
 def test_exact_cells_fp64_theta_beats_fp32_rounding():
