@@ -1477,11 +1477,19 @@ k_finish_lines(const double *__restrict__ raw, int n_ref, double *__restrict__ g
                double *__restrict__ result_dst, volatile unsigned long long *flag, unsigned long long seq) {
     const int lane = threadIdx.x;
     double g0 = 0.0, g1 = 0.0;
-    for (int k = 0; k < n_ref; ++k)
-        if (lane < kRawLines) {
-            g0 += raw[(int64_t)k * kRawStride + lane * kSubStride];
-            g1 += raw[(int64_t)k * kRawStride + lane * kSubStride + 1];
-        }
+    typedef double double2_v __attribute__((ext_vector_type(2)));
+    const int line = lane < kRawLines ? lane : kRawLines - 1;  // unconditional 16-byte loads, masked afterwards (see k_finish_raw)
+    double2_v a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = double2_v{0.0, 0.0};
+        if (k < n_ref) a[k] = *reinterpret_cast<const double2_v *>(raw + (int64_t)k * kRawStride + line * kSubStride);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        g0 += lane < kRawLines ? a[k].x : 0.0;
+        g1 += lane < kRawLines ? a[k].y : 0.0;
+    }
     g0 = wave_sum_lane63(g0);
     g1 = wave_sum_lane63(g1);
     if (result_dst && lane < 8) result_dst[lane] = result_src[lane];
@@ -1612,10 +1620,30 @@ k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__rest
              volatile unsigned long long *flag = nullptr, unsigned long long seq = 0) {
     const int lane = threadIdx.x;
     double v[4][6];
+    // every lane loads ITS line's six doubles as three 16-byte loads, all issued before the first use (lanes >= kRawLines re-read
+    // the last line and are zeroed by a select: `lane < 32 ? raw[..] : 0` put each of the 6 x n_ref loads into an exec-masked
+    // block with its own s_waitcnt -- six dependent round trips in a kernel that has only this one wave)
+    typedef double double2_v __attribute__((ext_vector_type(2)));
+    const int line = lane < kRawLines ? lane : kRawLines - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[k][q] = 0.0;
+        if (k < op.n_ref) {  // uniform
+            const double2_v *src = reinterpret_cast<const double2_v *>(raw + (int64_t)k * kRawStride + line * kSubStride);
+            const double2_v a = src[0], b = src[1], c = src[2];
+            v[k][0] = a.x;
+            v[k][1] = a.y;
+            v[k][2] = b.x;
+            v[k][3] = b.y;
+            v[k][4] = c.x;
+            v[k][5] = c.y;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) v[k][q] = (k < op.n_ref && lane < kRawLines) ? raw[(int64_t)k * kRawStride + lane * kSubStride + q] : 0.0;
+        for (int q = 0; q < 6; ++q) v[k][q] = lane < kRawLines ? v[k][q] : 0.0;
     const double v_orig = op.normalized ? orig_value<true>(op, stat) : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
