@@ -54,12 +54,19 @@ struct HandleEvalState {
     const float *last_iwe[4];
     uint64_t generation;  // bumped whenever the packed events / work list (and with them device pointers) change
     int profiling;
+    int deterministic;  // (read only: part of the key of a captured launch sequence)
 };
 __attribute__((visibility("hidden"))) void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out);
 __attribute__((visibility("hidden"))) void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in);
 // cmax_flow.hip, for the patch plan: fp64 voxel and (when the single-launch tiled chain ran: *wrote_v32) its fp32 copy
 __attribute__((visibility("hidden"))) int voxel_construct_f64_f32(const double *F, int Tn, int t0, int H, int W, int scheme, double *V,
                                                                float *V32, bool *wrote_v32, hipStream_t s);
+// ... and the adjoint sweeps (gV / dgV in, gradient in bin t0 out); det: order-free step kernels (deterministic handles)
+__attribute__((visibility("hidden"))) int voxel_construct_adj_f64(const double *V, int Tn, int t0, int H, int W, int scheme, double *gV, hipStream_t s,
+                                                               bool det);
+__attribute__((visibility("hidden"))) int voxel_construct_adj_tan_f64(const double *V, const double *dV, int Tn, int t0, int H, int W, int scheme,
+                                                                   double *gV, double *dgV, hipStream_t s, bool det);
+__attribute__((visibility("hidden"))) bool handle_is_deterministic(cmax_handle_t h);
 
 // ---- wave / block reductions (64-wide) -------------------------------------------------------
 // DPP on the VALU instead of ds_bpermute shuffles (~16 cycles each on gfx950): 4 row shifts, then lane 15 of

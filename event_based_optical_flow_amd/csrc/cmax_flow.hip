@@ -251,9 +251,11 @@ __device__ __forceinline__ void flow_step_adj_pixel(const T *__restrict__ F, int
 // 260 x 346 field (1.8M atomics); the jobs of a launch (both time directions) run one after the other in the workgroup,
 // so two jobs may share their destination (the last step: both chains arrive at bin t0).
 
-template <typename T, int SCHEME>
+// DET (deterministic handles, through the patch plan): no LDS atomics -- every destination pixel evaluates the scatter of its
+// (at most five) source pixels itself and keeps what lands on it, in a fixed order (see k_flow_step_adj_dual).
+template <typename T, int SCHEME, bool DET = false>
 __global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_tiled(StepJobs<T> jobs, int n_jobs, int H, int W, T tau) {
-    __shared__ T acc[2][kAdjTileH * kAdjTileW];
+    __shared__ T acc[2][DET ? 1 : kAdjTileH * kAdjTileW];
     const int64_t hw = (int64_t)H * W;
     const int tiles_w = (W + kAdjTileW - 1) / kAdjTileW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
@@ -266,6 +268,28 @@ __global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_tiled(StepJobs<T>
         const T *__restrict__ gout = jobs.gout[y];
         T *__restrict__ dst = jobs.dst[y];
         const T s = jobs.s[y];
+        auto U = [&](int r, int c) { return s * F[(int64_t)r * W + c]; };
+        auto V = [&](int r, int c) { return s * F[hw + (int64_t)r * W + c]; };
+        if (DET) {
+            for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjThreads) {
+                const int a = q / kAdjTileW, b = q - a * kAdjTileW, di = R0 + a, dj = C0 + b;
+                if (di >= H || dj >= W) continue;
+                T au = (T)0, av = (T)0;
+                auto GU = [&](int r, int c, T val) { if (r == di && c == dj) au += val; };
+                auto GV = [&](int r, int c, T val) { if (r == di && c == dj) av += val; };
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {  // sources: above, left, the pixel itself, right, below
+                    const int i = di + (k == 0 ? -1 : (k == 4 ? 1 : 0)), j = dj + (k == 1 ? -1 : (k == 3 ? 1 : 0));
+                    if ((unsigned)i >= (unsigned)H || (unsigned)j >= (unsigned)W) continue;
+                    const int64_t p = (int64_t)i * W + j;
+                    flow_step_adj_core<T, SCHEME>(U, V, GU, GV, i, j, H, W, tau, gout[p], gout[hw + p]);
+                }
+                const int64_t p = (int64_t)di * W + dj;
+                dst[p] += au;
+                dst[hw + p] += av;
+            }
+            continue;
+        }
         for (int q = threadIdx.x; q < kAdjTileH * kAdjTileW; q += kAdjThreads) {
             acc[0][q] = (T)0;
             acc[1][q] = (T)0;
@@ -274,8 +298,6 @@ __global__ void __launch_bounds__(kAdjThreads) k_flow_step_adj_tiled(StepJobs<T>
         for (int q = threadIdx.x; q < RH * RW; q += kAdjThreads) {
             const int a = q / RW, b = q - a * RW, i = R0 - 1 + a, j = C0 - 1 + b;
             if ((unsigned)i >= (unsigned)H || (unsigned)j >= (unsigned)W) continue;
-            auto U = [&](int r, int c) { return s * F[(int64_t)r * W + c]; };
-            auto V = [&](int r, int c) { return s * F[hw + (int64_t)r * W + c]; };
             auto GU = [&](int r, int c, T val) {
                 const int lr = r - R0, lc = c - C0;
                 if ((unsigned)lr < (unsigned)kAdjTileH && (unsigned)lc < (unsigned)kAdjTileW) atomic_add(&acc[0][lr * kAdjTileW + lc], val);
@@ -411,7 +433,7 @@ int voxel_construct(const T *F, int Tn, int t0, int H, int W, int scheme, T *V, 
 // each step adding J^T gV[neighbour] into gV[i] (atomics); step j of both chains shares a launch, the chains are
 // aligned so that they reach bin t0 in the same (last) launch.
 template <typename T>
-int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T *gV, T *gF, hipStream_t s) {
+int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T *gV, T *gF, hipStream_t s, bool det = false) {
     const int64_t sz = 2 * (int64_t)H * W;
     const T tau = (T)(1.0 / (double)Tn);
     const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
@@ -436,8 +458,12 @@ int voxel_construct_adj(const T *V, int Tn, int t0, int H, int W, int scheme, T 
         // the two chains write different bins until the last step, where both arrive at bin t0 (then one workgroup
         // runs both jobs of its tile one after the other)
         const dim3 agrid(tiles, (n == 2 && jobs.dst[0] != jobs.dst[1]) ? 2 : 1);
-        if (scheme == CMAX_SCHEME_BURGERS)
+        if (scheme == CMAX_SCHEME_BURGERS && det)
+            hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_BURGERS, true>), agrid, dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
+        else if (scheme == CMAX_SCHEME_BURGERS)
             hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_BURGERS>), agrid, dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
+        else if (det)
+            hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_UPWIND, true>), agrid, dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
         else
             hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_UPWIND>), agrid, dim3(kAdjThreads), 0, s, jobs, n, H, W, tau);
         CMAX_CHECK_LAUNCH();
@@ -488,7 +514,8 @@ int voxel_construct_tan(const T *F, const T *dF, int Tn, int t0, int H, int W, i
 // Adjoint sweep on dual numbers: gV / dgV hold (dL/dV, its tangent) on entry and are clobbered; gF = dL/dF (the
 // first-order gradient, as voxel_construct_adj gives it) and dgF = its directional derivative along dF.
 template <typename T>
-int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int W, int scheme, T *gV, T *dgV, T *gF, T *dgF, hipStream_t s) {
+int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int W, int scheme, T *gV, T *dgV, T *gF, T *dgF, hipStream_t s,
+                            bool det = false) {
     const int64_t sz = 2 * (int64_t)H * W;
     const T tau = (T)(1.0 / (double)Tn);
     const int nb = t0, nf = Tn - 1 - t0, nstep = nb > nf ? nb : nf;
@@ -507,8 +534,12 @@ int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int 
         }
         // the two chains write different bins until the last step, where both arrive at bin t0
         const dim3 dgrid(div_up(H, kAdjTileH) * div_up(W, kAdjTileW), (n == 2 && jobs.dst[0] != jobs.dst[1]) ? 2 : 1);
-        if (scheme == CMAX_SCHEME_BURGERS)
+        if (scheme == CMAX_SCHEME_BURGERS && det)
+            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_BURGERS, true>), dgrid, dim3(kAdjDualThreads), 0, s, jobs, n, H, W, tau);
+        else if (scheme == CMAX_SCHEME_BURGERS)
             hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_BURGERS>), dgrid, dim3(kAdjDualThreads), 0, s, jobs, n, H, W, tau);
+        else if (det)
+            hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_UPWIND, true>), dgrid, dim3(kAdjDualThreads), 0, s, jobs, n, H, W, tau);
         else
             hipLaunchKernelGGL((k_flow_step_adj_dual<T, CMAX_SCHEME_UPWIND>), dgrid, dim3(kAdjDualThreads), 0, s, jobs, n, H, W, tau);
         CMAX_CHECK_LAUNCH();
@@ -519,7 +550,7 @@ int voxel_construct_adj_tan(const T *V, const T *dV, int Tn, int t0, int H, int 
 }
 
 template int voxel_construct<float>(const float *, int, int, int, int, int, float *, hipStream_t, float *, bool *);
-template int voxel_construct_adj<float>(const float *, int, int, int, int, int, float *, float *, hipStream_t);
+template int voxel_construct_adj<float>(const float *, int, int, int, int, int, float *, float *, hipStream_t, bool);
 
 }  // namespace cmax
 
@@ -529,6 +560,13 @@ namespace cmax {
 // plan-internal: fp64 voxel and, when the tiled kernel ran, its fp32 copy in the same launch (*wrote_v32)
 int voxel_construct_f64_f32(const double *F, int Tn, int t0, int H, int W, int scheme, double *V, float *V32, bool *wrote_v32, hipStream_t s) {
     return voxel_construct<double>(F, Tn, t0, H, W, scheme, V, s, V32, wrote_v32);
+}
+// plan-internal: the adjoint sweeps with the order-free step kernels (deterministic handles)
+int voxel_construct_adj_f64(const double *V, int Tn, int t0, int H, int W, int scheme, double *gV, hipStream_t s, bool det) {
+    return voxel_construct_adj<double>(V, Tn, t0, H, W, scheme, gV, nullptr, s, det);
+}
+int voxel_construct_adj_tan_f64(const double *V, const double *dV, int Tn, int t0, int H, int W, int scheme, double *gV, double *dgV, hipStream_t s, bool det) {
+    return voxel_construct_adj_tan<double>(V, dV, Tn, t0, H, W, scheme, gV, dgV, nullptr, nullptr, s, det);
 }
 }  // namespace cmax
 

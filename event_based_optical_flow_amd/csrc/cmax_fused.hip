@@ -532,6 +532,29 @@ static_assert(kScratch >= 64 + kWinMaxW + 2, "scratch must hold a per-lane 2x2 f
 // unconditionally (clamped index), pin() every value, select afterwards: the loads are then issued back to back.
 __device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
 
+// Stage the ROWS x COLS window of `img` whose top-left pixel is (r0, c0) into an LDS tile of row pitch LD floats, zero outside
+// the image.  All of a thread's loads are issued before its first LDS store (see pin(): `in ? img[..] : 0` per iteration is one
+// memory round trip per iteration).  256 threads.
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void stage_tile(float (*tile)[LD], const float *__restrict__ img, int r0, int c0, int H, int W) {
+    constexpr int kN = ROWS * COLS, kIt = (kN + 255) / 256;
+    float x[kIt];
+#pragma unroll
+    for (int u = 0; u < kIt; ++u) {
+        const int q = threadIdx.x + 256 * u, a = q / COLS, b = q - a * COLS;
+        const int r = min(max(r0 + a, 0), H - 1), c = min(max(c0 + b, 0), W - 1);
+        x[u] = img[(int64_t)r * W + c];
+    }
+#pragma unroll
+    for (int u = 0; u < kIt; ++u) pin(x[u]);
+#pragma unroll
+    for (int u = 0; u < kIt; ++u) {
+        const int q = threadIdx.x + 256 * u, a = q / COLS, b = q - a * COLS;
+        const int r = r0 + a, c = c0 + b;
+        if (q < kN) tile[a][b] = ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? x[u] : 0.f;
+    }
+}
+
 // 16 bytes of zeros, written through the L2 (sc1): see the deferred-statistics K3
 typedef float float4_v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_zero4_sc1(float *p) {
@@ -880,11 +903,7 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
     const int tiles_w = (W + kGmTileW - 1) / kGmTileW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int r0 = tr * kGmTileH - 2, c0 = tc * kGmTileW - 2;
-    for (int q = threadIdx.x; q < (kGmTileH + 4) * (kGmTileW + 4); q += 256) {
-        const int a = q / (kGmTileW + 4), b = q - a * (kGmTileW + 4);
-        const int r = r0 + a, c = c0 + b;
-        tile[a][b] = ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? img[(int64_t)r * W + c] : 0.f;
-    }
+    stage_tile<kGmTileH + 4, kGmTileW + 4>(tile, img, r0, c0, H, W);
     __syncthreads();
     if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
@@ -972,10 +991,7 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
     const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
     const int i0 = omit ? 1 : 0;
     auto in_img = [&](int r, int c) { return (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W; };
-    for (int q = threadIdx.x; q < (TH + 8) * (TW + 8); q += 256) {
-        const int a = q / (TW + 8), b = q - a * (TW + 8), r = R0 - 4 + a, c = C0 - 4 + b;
-        t_i[a][b] = in_img(r, c) ? img[(int64_t)r * W + c] : 0.f;
-    }
+    stage_tile<TH + 8, TW + 8>(t_i, img, R0 - 4, C0 - 4, H, W);
     __syncthreads();
     zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
@@ -1074,10 +1090,7 @@ k_blur_stats_adj_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int
     const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
     const int i0 = omit ? 1 : 0;
     auto in_img = [&](int r, int c) { return (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W; };
-    for (int q = threadIdx.x; q < (TH + 4) * (TW + 4); q += 256) {
-        const int a = q / (TW + 4), b = q - a * (TW + 4), r = R0 - 2 + a, c = C0 - 2 + b;
-        t_i[a][b] = in_img(r, c) ? img[(int64_t)r * W + c] : 0.f;
-    }
+    stage_tile<TH + 4, TW + 4>(t_i, img, R0 - 2, C0 - 2, H, W);
     __syncthreads();
     zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
@@ -2212,6 +2225,8 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
     });
 }
 
+bool handle_is_deterministic(cmax_handle_t h) { return h && h->deterministic; }
+
 void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out) {
     out->cur_buf = h->cur_buf;
     out->zero_mask[0] = h->zero_mask[0];
@@ -2223,6 +2238,7 @@ void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out) {
     for (int k = 0; k < 4; ++k) out->last_iwe[k] = h->last_iwe[k];
     out->generation = h->generation;
     out->profiling = h->profiling ? 1 : 0;
+    out->deterministic = h->deterministic ? 1 : 0;
 }
 
 void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in) {

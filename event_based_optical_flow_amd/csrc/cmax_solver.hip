@@ -274,7 +274,7 @@ int backward_motion(cmax_patch_plan_s *p, const double **gx64, const float **gx3
     }
     const double *gflow = p->gacc64;
     if (d.time_aware) {  // the sweep leaves dL/dF in bin t0 of the gradient voxel: read it there
-        int rc = cmax_voxel_construct_adj(p->vox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, nullptr, s);
+        int rc = voxel_construct_adj_f64(p->vox64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, s, handle_is_deterministic(p->handle));
         if (rc) return rc;
         gflow = p->gacc64 + (int64_t)d.t0 * p->nflow;
     }
@@ -363,7 +363,7 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
         CMAX_CHECK_LAUNCH();
     }
     // the sweep leaves d(dL/dF) in bin t0 of the tangent gradient voxel: the interpolation adjoint reads it there
-    rc = cmax_voxel_construct_adj_tan(p->vox64, p->dvox64, CMAX_F64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->dgacc64, nullptr, nullptr, s);
+    rc = voxel_construct_adj_tan_f64(p->vox64, p->dvox64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->dgacc64, s, handle_is_deterministic(p->handle));
     if (rc) return rc;
     rc = cmax_patch_to_dense(p->dgacc64 + (int64_t)d.t0 * p->nflow, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
     if (rc) return rc;
@@ -433,6 +433,7 @@ uint64_t state_key(const HandleEvalState &st, int kind) {
     k = k * 1000003u + st.zero_mask[0];
     k = k * 1000003u + st.zero_mask[1];
     k = k * 1000003u + (uint64_t)st.orig_valid;
+    k = k * 1000003u + (uint64_t)st.deterministic;
     k = k * 1000003u + (uint64_t)(st.orig_cost + 7);
     k = k * 1000003u + (uint64_t)(st.orig_omit + 7);
     k = k * 1000003u + sb;

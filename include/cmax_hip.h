@@ -354,8 +354,11 @@ int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, cons
  * kernels.  Same arithmetic per event, same parity (1e-4 of the reference); slower: no fused image kernels, one pair
  * of global atomics per event for the flow gradient (dense 5M events: ~10x an evaluation), 40 B per pixel more HBM.
  * cmax_objective_hvp is covered as well (round 3: integer tangent-vote images, integer accumulation of the second-order gather).
- * Not covered: the patch plan's own kernels (interpolation adjoint, voxel chain); across ranks (cmax_objective_dist) the result
- * is as repeatable as RCCL's reduction order.                                                                      */
+ * A patch plan on a deterministic handle (cmax_patch_plan_evaluate / _hvp) is covered too: the interpolation and its adjoint are
+ * gathers, the adjoint sweeps of the voxel chain run order-free step kernels (every destination pixel evaluates the scatter of
+ * its five sources itself instead of LDS atomics), the tail is one workgroup.  Not covered: the stand-alone leaf entries
+ * cmax_flow_step_adj / cmax_voxel_construct_adj[_tan] (no handle to read the mode from; fp64 LDS atomics, last-bit differences);
+ * across ranks (cmax_objective_dist) the result is as repeatable as RCCL's reduction order.                          */
 int cmax_set_deterministic(cmax_handle_t h, int enable);
 int cmax_get_deterministic(cmax_handle_t h, int *enabled);
 

@@ -139,3 +139,49 @@ def test_hvp_bit_repeatable(model, cost, sigma, Tn):
     assert rel_max(Hu_default, Hu) <= 2e-4  # fp32 atomics / another summation order on the default side
     lhs, rhs = float((v * Hu).sum()), float((u * Hv).sum())
     assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1e-300), (lhs, rhs)  # <v, H u> = <u, H v>
+
+
+@pytest.mark.parametrize("tag", ["plain", "burgers"])
+def test_patch_plan_bit_repeatable(golden, tag):
+    """The patch plan (cmax_patch_plan_evaluate / _hvp: interpolation, Burgers voxel chain and their adjoints around the fused
+    objective) on a deterministic handle: three FRESH handles + plans, two calls each, identical bytes in loss, gradient and
+    Hessian-vector product -- the adjoint sweeps of the voxel chain then run their order-free step kernels (no LDS atomics) --
+    and the same numbers as the default mode up to its summation order."""
+    from event_based_optical_flow_amd.solver import PatchFlowObjective
+
+    g = golden("solver_objective")
+    k = f"{tag}_s3"
+    size = tuple(int(v) for v in g["image_size"])
+    ev = g["events"]
+    x = np.asarray(g[k + "__x"], dtype=np.float64).reshape(-1)
+    v = np.random.default_rng(3).normal(size=x.shape)
+
+    def run(deterministic):
+        h = E.CMaxHandle(size)
+        h.set_deterministic(deterministic)
+        h.set_events(ev, time_bin=10 if tag == "burgers" else 0)
+        obj = PatchFlowObjective(h, ev[:, 2].max() - ev[:, 2].min(), g[k + "__patch_image_size"], g[k + "__patch_size"],
+                                 g[k + "__sliding_window"], g[tag + "__patch_shift"], cost="hybrid",
+                                 cost_with_weight={"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01},
+                                 blur_sigma=1, time_aware=(tag == "burgers"), time_bin=10, flow_interpolation="burgers",
+                                 t0_flow_location="middle")
+        assert obj.has_native_plan
+        outs = []
+        for _ in range(2):
+            loss, grad = obj.value_and_grad_numpy(x)
+            hv = obj.hvp_numpy(x, v)
+            outs.append((np.float64(loss).tobytes(), np.asarray(grad).tobytes(), np.asarray(hv).tobytes()))
+        return outs, float(loss), np.asarray(grad), np.asarray(hv)
+
+    runs = [run(True) for _ in range(3)]
+    first = runs[0][0][0]
+    for outs, *_ in runs:
+        for o in outs:
+            assert o == first, "the patch plan on a deterministic handle produced different bits"
+    _, loss, grad, hv = runs[0]
+    _, loss_d, grad_d, hv_d = run(False)
+    assert abs(loss - g[k + "__loss"]) <= TOL * abs(g[k + "__loss"])
+    assert rel_max(grad, np.asarray(g[k + "__grad"]).reshape(-1)) <= TOL
+    assert abs(loss - loss_d) <= 1e-6 * abs(loss_d)
+    assert rel_max(grad, grad_d) <= 1e-5
+    assert rel_max(hv, hv_d) <= 2e-4
