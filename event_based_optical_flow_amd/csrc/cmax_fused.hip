@@ -150,6 +150,7 @@ struct cmax_handle_s {
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
     bool big = false;        // BIG segments: up to 4088 events each, event kernels of the b512 / b1024 namespaces (batches of >= 8M events)
     int seg_max = 2040;      // events per segment of the current work list (kSegMax, or 4088 for big segments)
+    bool small_acc = false;  // binned handle, owned groups of <= 3 groups per segment: the voxel K3 with kAccCellsDense accumulator cells (kGradOwnedSmall)
     bool owned = false;      // the work list gives every group (empty ones included) to exactly one segment, <= kAccCells / 256 groups each
     int *d_tile_start = nullptr;  // [ngroups + 1] first sorted event of every group (source tile, or (tile, time bin))
     // What the host reads back once per batch lives in ONE allocation, in this order: d_tmm (2 doubles) | d_flags (4 ints) |
@@ -520,7 +521,7 @@ constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3; 
 // RefArgs::stat_blocks workgroups of the grid are k_stats (they also write the loss), the others gather; nothing in the
 // gradient waits for the statistics: the chain factor is a constant and the mean comes from K1's vote sums (RefArgs::musum)
 constexpr int kFoldStatsInside = 4;
-constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2, kGradDet = 3;  // k_grad's VARIANT (see cmax_event_kernels.inc)
+constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2, kGradDet = 3, kGradOwnedSmall = 4;  // k_grad's VARIANT (see cmax_event_kernels.inc)
 constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
@@ -1732,6 +1733,7 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 static int grad_threads(const cmax_handle_s *h, int model) {
     static const int force = forced_ns("CMAX_GRAD_NS");
     if (h->big) return model == CMAX_MODEL_VOXEL ? 1024 : 512;
+    if (model == CMAX_MODEL_VOXEL && h->small_acc && h->owned && !force) return 512;
     if (force ? (force == 1024 && model == CMAX_MODEL_VOXEL) : (model == CMAX_MODEL_VOXEL && wide_groups(h))) return 1024;
     return (force ? force >= 512 : h->nseg > 512) ? 512 : 256;
 }
@@ -1779,7 +1781,9 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
                 CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradRuns);                \
             }                                                                 \
         } else if constexpr (MODEL == CMAX_MODEL_VOXEL) {                     \
-            if (owned) {                                                      \
+            if (owned && small) {                                             \
+                if constexpr (NS::kThr == 512 && !NS::kBig) { CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwnedSmall); } \
+            } else if (owned) {                                               \
                 CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwned);               \
             } else {                                                          \
                 CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradRuns);                \
@@ -1792,7 +1796,10 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     if (fold == kFoldDeferred) {                                                             \
         if constexpr (MODEL == CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); } \
     } else if (fold == kFoldStatsInside) {                                                   \
-        if constexpr (MODEL != CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); } \
+        if constexpr (MODEL == CMAX_MODEL_VOXEL && NS::kThr == 512 && !NS::kBig) {           \
+            if (small) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwnedSmall); } \
+            else { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); }            \
+        } else if constexpr (MODEL != CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); } \
     } else if (fold == kFoldStats) {                                                         \
         CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);                                              \
     } else if (fold == kFoldScale) {                                                         \
@@ -1807,6 +1814,8 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
         CMAX_LAUNCH_GRAD_FR(NS, false)   \
     }
     static const int force = forced_ns("CMAX_GRAD_NS");
+    // voxel, owned groups of <= 3 groups per segment: 512 threads x 4 events with the small accumulator array (see build_segments)
+    const bool small = MODEL == CMAX_MODEL_VOXEL && owned && h->small_acc && !h->big && !force;
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
         if (h->big) {  // segments of up to 4088 events
             if constexpr (MODEL == CMAX_MODEL_VOXEL) {
@@ -1814,6 +1823,8 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
             } else {
                 CMAX_LAUNCH_GRAD_NS(b512)
             }
+        } else if (small) {
+            CMAX_LAUNCH_GRAD_NS(t512)
         } else if (force ? (force == 1024 && MODEL == CMAX_MODEL_VOXEL) : (MODEL == CMAX_MODEL_VOXEL && wide_groups(h))) {  // measured: voxel K3 of cfg4 22.1 us (512 threads) -> 19.3 us
             if constexpr (MODEL == CMAX_MODEL_VOXEL) {
                 CMAX_LAUNCH_GRAD_NS(t1024)
@@ -2107,8 +2118,14 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         h->owned = fits;
     }
     h->row_seg_start.clear();
+    // Binned handles whose groups are dense (>= 480 events per (tile, bin) group on average: four groups would not fit a segment
+    // anyway): segments of <= 3 groups, so that the voxel K3 needs 768 accumulator cells per channel instead of 3072 -- 40 KB of LDS
+    // per workgroup instead of 58, i.e. FOUR 512-thread workgroups per CU with 4 events per thread instead of two 1024-thread ones
+    // with 2 (the per-thread fixed costs of K3 are spread over twice the events).  CMAX_SMALL_ACC=0 / 1 overrides (A/B runs).
+    static const int small_env = getenv("CMAX_SMALL_ACC") ? atoi(getenv("CMAX_SMALL_ACC")) : -1;
+    h->small_acc = T > 1 && h->owned && !h->big && (small_env >= 0 ? small_env != 0 : h->n >= (int64_t)480 * ngroups);
     if (h->owned) {
-        const int span_max = T == 1 ? (h->big ? 6 : 3) : kAccCells / 256, row_groups = h->ntc * T;  // dense: kAccCellsDense (x 2 for big segments)
+        const int span_max = T == 1 ? (h->big ? 6 : 3) : (h->small_acc ? kAccCellsDense / 256 : kAccCells / 256), row_groups = h->ntc * T;  // dense: kAccCellsDense (x 2 for big segments)
         for (int r0 = 0; r0 < ngroups; r0 += row_groups) {
             h->row_seg_start.push_back((int)segs.size());
             int g = r0;
@@ -2155,6 +2172,10 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     }
     close();
     h->nseg = (int)segs.size();
+    static const bool debug_segs = getenv("CMAX_DEBUG_SEGS") != nullptr;  // tools/probe_rounds.py
+    if (debug_segs)
+        fprintf(stderr, "[cmax] work list: n=%lld groups=%d segments=%d owned=%d big=%d small_acc=%d\n", (long long)h->n, ngroups, h->nseg, (int)h->owned,
+                (int)h->big, (int)h->small_acc);
     if (h->nseg > h->seg_cap) {
         dev_free(&h->d_segs);
         dev_free(&h->d_gpart);
