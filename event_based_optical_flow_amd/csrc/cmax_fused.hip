@@ -2094,8 +2094,43 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // (256 CUs x 3 resident workgroups, several rounds): measured (profiles/r03_ablation.txt 8) 20M events 104.3 -> 95.0 us per
     // evaluation, 64M events 323.6 -> 292.6; 5M events (1223 segments) 38.5 -> 38.2; below that fewer, longer workgroups LOSE
     // (2.5M events @720p 30.6 -> 33.1, 2M-event voxel batch 31.4 -> 33.5).
+    // Between 522k and 8M events the choice follows the work list itself (tools/probe_rounds.py, profiles/r03_ablation.txt 17): both
+    // group-aligned cuts are counted, and big segments are taken when they need <= 4/11 of the standard cut's workgroups (720p: 4M
+    // events = 3600 one-tile segments of 1100 events vs 1200 three-tile ones, 41.5 -> 38.7 us; voxel T = 10: 4M events 47.1 -> 41.0)
+    // -- at a ratio of 2 .. 2.5 the standard cut wins (cfg5's shard 30.6 vs 33.1, cfg4 31.4 vs 33.5) -- or, from 4M events on, when
+    // the standard cut is not group-aligned at all (groups above 2040 events: 720p 7M 56.4 -> 47.9 us; cfg3 37.9 -> 36.9 us).
     static const int big_env = getenv("CMAX_BIG_SEG") ? atoi(getenv("CMAX_BIG_SEG")) : -1;
-    h->big = big_env >= 0 ? big_env != 0 : h->n >= (int64_t)8000000;
+    auto owned_count = [&](int cut, int span_max) -> int {  // segments of the group-aligned cut; -1: a group exceeds `cut`
+        for (int g = 0; g < ngroups; ++g)
+            if (group_start[g + 1] - group_start[g] > cut) return -1;
+        const int row_groups = h->ntc * T;
+        int cnt = 0;
+        for (int r0 = 0; r0 < ngroups; r0 += row_groups) {
+            int g = r0;
+            while (g < r0 + row_groups) {
+                const int gs = g;
+                int c = 0;
+                while (g < r0 + row_groups && g - gs < span_max && c + (group_start[g + 1] - group_start[g]) <= cut) {
+                    c += group_start[g + 1] - group_start[g];
+                    ++g;
+                }
+                ++cnt;
+            }
+        }
+        return cnt;
+    };
+    if (big_env >= 0) {
+        h->big = big_env != 0;
+    } else if (h->n >= (int64_t)8000000) {
+        h->big = true;
+    } else if (h->n < (int64_t)256 * kSegMax) {
+        h->big = false;
+    } else {
+        const bool small_std = T > 1 && h->n >= (int64_t)480 * ngroups;  // (see small_acc below)
+        const int std_n = owned_count(kSegMax, T == 1 ? 3 : (small_std ? kAccCellsDense / 256 : kAccCells / 256));
+        const int big_n = std_n >= 0 ? owned_count(4088, T == 1 ? 6 : kAccCells / 256) : -1;
+        h->big = std_n >= 0 ? (int64_t)std_n * 4 >= (int64_t)big_n * 11 : h->n >= (int64_t)4000000;
+    }
     h->seg_max = h->big ? 4088 : kSegMax;
     const int kSegCut = h->seg_max;
     int max_groups = T == 1 ? 3 : kAccCells / 256;

@@ -19,6 +19,9 @@ shapes = {
     "dense240p": dict(H=260, W=346, model="dense-flow", cost="image_variance", sigma=0.0, T=0, ns=[0.5, 1.0, 2.0]),
     "dense480p": dict(H=480, W=640, model="dense-flow", cost="image_variance", sigma=0.0, T=0, ns=[0.5, 1.0, 2.0, 3.0]),
     "dense720p_smallflow": dict(H=720, W=1280, model="dense-flow", cost="image_variance", sigma=0.0, T=0, flow=4, ns=[1.0, 2.5]),
+    "dense720p_hi": dict(H=720, W=1280, model="dense-flow", cost="image_variance", sigma=0.0, T=0, ns=[3.0, 4.0, 5.0, 6.0, 7.0]),
+    "dense480p_hi": dict(H=480, W=640, model="dense-flow", cost="image_variance", sigma=0.0, T=0, ns=[3.0, 4.0, 5.0, 6.0, 7.0]),
+    "voxel_hi": dict(H=260, W=346, model="dense-flow-voxel", cost="image_variance", sigma=1.0, T=10, ns=[3.0, 4.0, 5.0, 6.0, 7.0]),
     "voxel": dict(H=260, W=346, model="dense-flow-voxel", cost="image_variance", sigma=1.0, T=10, ns=[1.0, 1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 3.0]),
 }
 which = sys.argv[1:] or list(shapes)
