@@ -18,7 +18,7 @@ for w in cfg2 cfg3 cfg4 cfg5 cfg5_strong hbm; do
   bash tools/prof_pmc.sh $w --workload $w
   cp gpurun_out/pmc_$w.json $out/pmc_${w}_raw.json
 done
-for w in cfg2 cfg3 cfg5; do
+for w in cfg2 cfg3 cfg4 cfg5; do
   bash tools/prof_sq.sh $w --workload $w > $out/sq_$w.txt 2>&1
   cp gpurun_out/sq_$w.json $out/sq_$w.json
 done
