@@ -134,6 +134,13 @@ class CMaxHandle:
         check(self._lib.cmax_batch_info(self._h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(f), ctypes.byref(o)))
         return {"packed": n.value, "dropped": d.value, "fractional": bool(f.value), "owned_groups": bool(o.value)}
 
+    def work_list_info(self) -> Dict[str, int]:
+        """{"segments", "segment_events", "small_accumulators"} of the work list the last set_events / set_time_bins cut
+        (cmax_work_list_info): one workgroup of the event kernels per segment; segment_events is 2040 or 4088 (big segments)."""
+        n, e, a = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.cmax_work_list_info(self._h, ctypes.byref(n), ctypes.byref(e), ctypes.byref(a)))
+        return {"segments": n.value, "segment_events": e.value, "small_accumulators": bool(a.value)}
+
     def set_time_bins(self, time_bin: int):
         check(self._lib.cmax_set_time_bins(self._h, int(time_bin), F._stream()))
         self.time_bin = int(time_bin)

@@ -2134,7 +2134,8 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     h->seg_max = h->big ? 4088 : kSegMax;
     const int kSegCut = h->seg_max;
     int max_groups = T == 1 ? 3 : kAccCells / 256;
-    const bool free_cut = h->n > (int64_t)1024 * kSegMax;
+    static const int free_env = getenv("CMAX_FREE_CUT") ? atoi(getenv("CMAX_FREE_CUT")) : -1;  // tuning only
+    const bool free_cut = free_env >= 0 ? free_env != 0 : h->n > (int64_t)1024 * kSegMax;
     // batches far below one full segment per CU (the solver's 30k-event slices): a workgroup walks its events
     // 8 (4) per thread, so 2040-event segments leave 15 workgroups with long serial work on a 256-CU chip.
     // Cap the segment at n / 512 (>= 256 events): cfg1-shaped K3 13 -> 5 us.
@@ -3575,6 +3576,14 @@ int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int 
     if (n_dropped) *n_dropped = h->n_dropped;
     if (has_fractional) *has_fractional = h->has_frac ? 1 : 0;
     if (owned_groups) *owned_groups = h->owned ? 1 : 0;
+    return 0;
+}
+
+int cmax_work_list_info(cmax_handle_t h, int *n_segments, int *segment_events, int *small_accumulators) {
+    CMAX_REQUIRE(h != nullptr, "work_list_info");
+    if (n_segments) *n_segments = h->nseg;
+    if (segment_events) *segment_events = h->seg_max;
+    if (small_accumulators) *small_accumulators = h->small_acc ? 1 : 0;
     return 0;
 }
 

@@ -390,6 +390,12 @@ int cmax_copy_iwe(cmax_handle_t h, int k, float *iwe_out, cmax_stream_t stream);
  * any source coordinate is fractional; whether the work list gives every group to one segment (owned groups:
  * single-reference dense / voxel gradients are then stored, not added).  Any pointer may be NULL.            */
 int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int *has_fractional, int *owned_groups);
+/* The work list cmax_set_events / cmax_set_time_bins cut for the event kernels (one workgroup per segment): number of
+ * segments; segment_events = the most events a segment holds (2040, or 4088 for BIG segments: batches of >= 8M events, and
+ * smaller ones whose group sizes ask for it -- DESIGN.md section 2); small_accumulators = 1 when a binned list was cut at
+ * three (tile, bin) groups per segment for the voxel gradient kernel with the small LDS accumulator array.  Any pointer may
+ * be NULL.  (Introspection for tests and tuning: results do not depend on the cut.)                                       */
+int cmax_work_list_info(cmax_handle_t h, int *n_segments, int *segment_events, int *small_accumulators);
 
 /* Introspection for tests / bench: number of packed events, HBM bytes held by the handle.     */
 int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_bytes);

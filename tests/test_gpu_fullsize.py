@@ -1,8 +1,9 @@
 """Full-size parity: the BASELINE configurations at THEIR sizes against the fp64 oracle.
 
-Above ~2.1M events the host switches the event kernels to 512-thread workgroups (1024 for the voxel K3); these tests
-run exactly the instantiations the bench numbers come from -- t256 2-DoF deferred (cfg2), t512 dense grad-mag
-(cfg3), t1024 voxel with blur (cfg4), t512 dense variance on a sparse 720p batch (cfg5 shard) -- and compare IWE,
+The host picks workgroup size, segment size and accumulator layout from the batch; these tests
+run exactly the instantiations the bench numbers come from -- t512 2-DoF deferred (cfg2), b512 dense grad-mag on big segments
+(cfg3), t512 voxel with blur and small accumulators (cfg4), t512 dense variance on a sparse 720p batch (cfg5 shard), b512 at 20M
+events (cfg5) -- plus the cuts no BASELINE configuration reaches (test_work_list_variants_against_the_oracle) and compare IWE,
 loss and gradient with oracle/cmax_oracle.c (scalar C, ~6e7 events/s: seconds per case).
 
 Tolerance (BASELINE north_star): 1e-4 relative, fp32 device path against the fp64 oracle -- for the IWE, the loss and
@@ -130,6 +131,49 @@ def test_cfg5_shard_full_size_with_gradient():
     ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
     bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
     check("cfg5 shard 2.5M 720x1280 dense variance", h, res, grad, ref, bound, n_amb)
+
+
+WORK_LISTS = [
+    # (tag, size, n, T, model, expected segment_events, expected small accumulators, segments above 1024?)
+    ("voxel 1.7M 260x346: standard segments of 4 groups, 512-thread K3 with 12-group accumulators", (260, 346), 1_700_000, 10, "dense-flow-voxel", 2040, False, False),
+    ("voxel 3M 480x640: 8 groups per segment, more than 1024 segments -> 1024-thread K3", (480, 640), 3_000_000, 10, "dense-flow-voxel", 2040, False, True),
+    ("voxel 4M 260x346: one group per standard segment -> BIG segments of 3 groups, b1024 K3", (260, 346), 4_000_000, 10, "dense-flow-voxel", 4088, False, True),
+    ("dense 4M 720p: one tile per standard segment -> BIG segments of 3 tiles, owned b512 K3", (720, 1280), 4_000_000, 0, "dense-flow", 4088, False, True),
+    ("dense 3M 720p: two tiles per standard segment stay", (720, 1280), 3_000_000, 0, "dense-flow", 2040, False, True),
+]
+
+
+@pytest.mark.parametrize("tag,size,n,Tn,model,seg_events,small,wide", WORK_LISTS, ids=[w[0].split(":")[0] for w in WORK_LISTS])
+def test_work_list_variants_against_the_oracle(tag, size, n, Tn, model, seg_events, small, wide):
+    """Round 3: the host picks the segment size (2040 / 4088 events) and the voxel K3's accumulator array from the group sizes of
+    the work list (profiles/r03_ablation.txt 14 / 17).  Each case asserts the cut it was written for
+    (cmax_work_list_info) and holds loss, IWE and gradient of a variance objective to the oracle -- these are instantiations of
+    the event kernels that no BASELINE configuration reaches: the owned b512 / b1024 K3, the 1024-thread voxel K3 with the large
+    accumulators, the 512-thread one below 1024 segments."""
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=51)
+    f0 = E.utils.generate_smooth_flow(size, 12, seed=1051)
+    motion = orc.construct_dense_flow_voxel(f0 / 12.0, Tn, "burgers", "middle") * 12.0 if Tn else f0
+    h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
+    info = h.work_list_info()
+    assert info["segment_events"] == seg_events and info["small_accumulators"] == small, (tag, info)
+    assert (info["segments"] > 1024) == wide, (tag, info)
+    assert h.batch_info()["owned_groups"]
+    desc = E.make_descriptor("image_variance", model, sigma=0.0, time_bin=Tn)
+    ref = orc.objective(ev, motion, model, size, cost="image_variance", sigma=0)
+    bound, n_amb = ambiguity_bound(ev, motion, model, size, raw_image_grad(ref, 0))
+    res, grad = h.evaluate(desc, motion)
+    check(tag, h, res, grad, ref, bound, n_amb)
+
+
+def test_work_list_rule_on_the_bench_configurations():
+    """cfg2 (2674 events per tile: not group-aligned, 1M events) keeps standard segments, cfg3 (4170 per tile, 5M events) gets big
+    ones, cfg4 (535 events per (tile, bin) group) the small accumulators, cfg5's shard (694 per tile) standard segments."""
+    cases = [((260, 346), 1_000_000, 0, 2040, False), ((480, 640), 5_000_000, 0, 4088, False), ((260, 346), 2_000_000, 10, 2040, True),
+             ((720, 1280), 2_500_000, 0, 2040, False)]
+    for size, n, Tn, seg_events, small in cases:
+        ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
+        info = E.CMaxHandle(size).set_events(ev, time_bin=Tn).work_list_info()
+        assert info["segment_events"] == seg_events and info["small_accumulators"] == small, (size, n, Tn, info)
 
 
 def test_cfg5_two_time_slices_of_5m_against_the_oracle():
