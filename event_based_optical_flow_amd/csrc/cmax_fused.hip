@@ -66,13 +66,14 @@ constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit w
 constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (voxel K3): 12 (tile, bin) groups
 constexpr int kAccCellsDense = 768;           // the same for the dense K3 with owned tiles: 3 source tiles
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
+constexpr int kShiftWordsMax = 512;           // words of cell offsets per (reference time, segment): 4 bits per slot of a big segment
 // (votes are accumulated as signed fixed point in the LDS windows: 12.20, big segments 13.19 -- kFixNS of cmax_event_kernels.inc)
 
 struct EvView {
     const uint2 *ev;      // .x = row | col << 12 | bin << 24 ; .y = bits of fp32 tau = (t - tmin) / (tmax - tmin)
     const float *rx;      // fractional residual of the source coordinate (nullptr if integral)
     const float *ry;
-    int64_t n;
+    const double *tau64;  // normalised time in fp64, same order as `ev`: read only for the few events whose cell is decided in fp64 (warp_exact)
 };
 
 struct WarpParams {
@@ -97,6 +98,8 @@ struct RefArgs {
     float *zero[4];   // K3, deferred statistics: vote image of the NEXT evaluation to clear (or null)
     int k0;           // index of the first reference time of this launch (statistics slot, partial-sum offset)
     int4 *win;        // [n_ref][nseg] LDS windows: written by K1, read by K3 of the same evaluation (or null)
+    unsigned *shifts; // [n_ref][nseg][kSlots / 8] cell offsets of the events K1 decided in fp64 (phase_warp), 8 slots per word; valid where Window::bmask says so
+    int windows_only; // K1: publish the windows (and offsets) and return -- for a K3 whose vote this was not (cmax_objective_finish)
     // K1, blurred variance with a gradient: sum_p I[p] B[p] (B = blur^T 1_Omega = b(r) b(c)) = the sum of the blurred image over
     // Omega, accumulated while the votes are flushed -- the image kernel then knows the mean before it has blurred anything
     double *musum[4];        // kMuLines accumulators (one 128-byte line each) per reference time, or null
@@ -159,6 +162,7 @@ struct cmax_handle_s {
     int *d_active = nullptr;  // [ntiles] source pixels that hold events, per tile (un-binned order; written by k_tile_sort)
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int4 *d_win = nullptr;        // [4][nseg] LDS windows of the last objective vote (K1 -> K3 of the same evaluation)
+    unsigned *d_shifts = nullptr; // [4][nseg][kShiftWordsMax] cell offsets of the events that vote decided in fp64 (RefArgs::shifts)
     // what those windows were computed for: K3 reuses them only for the same motion / model / reference times
     const float *win_motion = nullptr;
     int win_model = -2, win_nref = 0, win_T = 0, win_normalize = 0;
@@ -415,6 +419,7 @@ struct Warped {
     float a, b;    // row / column fractions
     float dt;
     int src;       // source pixel linear index (un-padded), + bin * 2HW for voxel
+    float f0, f1;  // dense / voxel: the flow at the source pixel (phase_warp bounds the rounding of dt * f with it)
 };
 
 // MODEL: -1 none (orig_iwe), 0 2-DoF, 1 dense, 2 voxel
@@ -440,8 +445,10 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
         // per channel, instead of 64-bit per-lane pointer arithmetic (the field is < 4 GiB: checked by the host)
         const unsigned off = (unsigned)w.src * 4u;
         const char *m0 = reinterpret_cast<const char *>(wp.motion), *m1 = reinterpret_cast<const char *>(wp.motion + hw);
-        dx = fmaf(-w.dt, *reinterpret_cast<const float *>(m0 + off), dx);  // x' = x - dt*F[0,ix,iy], src/warp.py:305-306
-        dy = fmaf(-w.dt, *reinterpret_cast<const float *>(m1 + off), dy);
+        w.f0 = *reinterpret_cast<const float *>(m0 + off);
+        w.f1 = *reinterpret_cast<const float *>(m1 + off);
+        dx = fmaf(-w.dt, w.f0, dx);  // x' = x - dt*F[0,ix,iy], src/warp.py:305-306
+        dy = fmaf(-w.dt, w.f1, dy);
     }
     // floor(x' + 1e-6) = ix + floor(dx + 1e-6) exactly because ix is an integer
     // (bilinear_vote_tensor, src/event_image_converter.py:340-345)
@@ -454,22 +461,24 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
     return w;
 }
 
-// EXACT CELLS (round 3, 2-DoF).  The image is continuous across a cell border, the gradient is not (it takes its differences of
-// dL/dIWE from the event's own cell), and a 2-DoF gradient is ONE sum over all events: the ~70 of a million events whose
-// displacement lies within fp32 rounding of a border moved it by 6e-4 relative against the reference's fp64 value (the
-// reference's own fp32 path: 1.3e-3, tests/golden/cfg2_fp32_reference.npz).  The fp32 displacement of warp_one is off by at most
-// 2^-24 (|theta| + 5 |dx|) (rounding of tau, of tau - d, of the time scale, of theta, of the product, of the + 1e-6); an event
-// whose fraction a or b comes closer than that to 0 or 1 -- phase_warp tests |a - 1/2| > 1/2 - m, two VALU instructions per
-// axis -- is warped again here, with the arithmetic of src/warp.py:506-515 + src/event_image_converter.py:340 in fp64 on the
-// 32-bit normalised time of tau_refined and the caller's fp64 theta.  ~5e-5 of the events.  (Dense / voxel: the flow itself is
-// fp32 on the device, and their gradients are per pixel, not one sum over the batch.)
-template <bool FRAC>
-__device__ __forceinline__ Warped warp_exact_2dof(const EvView &ev, uint2 e, int64_t i, const WarpParams &wp, double thd0, double thd1) {
+// EXACT CELLS (round 3: 2-DoF; round 4: every model).  The image is continuous across a cell border, the gradient is not (it takes
+// its differences of dL/dIWE from the event's own cell): an event whose displacement lies within fp32 rounding of a border falls
+// on the other side in any fp32 evaluation, and its term of the gradient then comes from the wrong side of the kink -- ~70 of a
+// million events moved the 2-DoF gradient (ONE sum over all events) by 6e-4 relative against the reference's fp64 value (the
+// reference's own fp32 path: 1.3e-3, tests/golden/cfg2_fp32_reference.npz), and a flow gradient by more than 1e-4 in the pixels
+// such events come from (2-5 of 0.6-1.8M entries at the BASELINE sizes).  The fp32 displacement of warp_one is off by at most
+// 7 * 2^-24 |motion| max(period, 1) max(1, |d|, |1 - d|) (rounding of tau, of tau - d, of the time scale, of the product, of the
+// + 1e-6); an event whose fraction a or b comes closer than exact_margin to 0 or 1 is warped again here BY K1, with the arithmetic of
+// src/warp.py:304-307 / 506-515 + src/event_image_converter.py:340 in fp64: the fp64 normalised time (EvView::tau64, a load only
+// these events make), the caller's fp64 theta (2-DoF), the flow as the device holds it (fp32 values, fp64 arithmetic) -- 1e-5 ..
+// 1e-4 of the events -- and K1 publishes the cell's offset from the fp32 one for K3 (phase_warp).
+template <int MODEL, bool FRAC>
+__device__ __forceinline__ Warped warp_exact(const EvView &ev, unsigned ex, int64_t i, double tau, double period, const WarpParams &wp, double m0, double m1) {
     Warped w;
-    const int ix = (int)(e.x & 0xFFFu), iy = (int)((e.x >> 12) & 0xFFFu);
-    const double period = wp.normalize ? 1.0 : wp.tmm[1] - wp.tmm[0];
-    const double dtd = (tau_refined(e) - (double)wp.d) * period;
-    const double ddx = fma(dtd, thd0, FRAC ? (double)ev.rx[i] : 0.0), ddy = fma(dtd, thd1, FRAC ? (double)ev.ry[i] : 0.0);
+    const int ix = (int)(ex & 0xFFFu), iy = (int)((ex >> 12) & 0xFFFu);
+    const double dtd = (tau - (double)wp.d) * period;
+    const double sgn = MODEL == CMAX_MODEL_2DOF ? 1.0 : -1.0;  // x' = x + dt theta (warp.py:514)  |  x' = x - dt F (warp.py:305)
+    const double ddx = fma(sgn * dtd, m0, FRAC ? (double)ev.rx[i] : 0.0), ddy = fma(sgn * dtd, m1, FRAC ? (double)ev.ry[i] : 0.0);
     const double fxd = fmin(fmax(floor(ddx + 1e-6), -8192.0), 8192.0), fyd = fmin(fmax(floor(ddy + 1e-6), -8192.0), 8192.0);
     w.a = (float)(ddx - fxd);
     w.b = (float)(ddy - fyd);
@@ -477,8 +486,18 @@ __device__ __forceinline__ Warped warp_exact_2dof(const EvView &ev, uint2 e, int
     w.col = iy + (int)fyd + wp.pw;
     w.dt = 0.f;
     w.src = 0;
+    w.f0 = 0.f;
+    w.f1 = 0.f;
     return w;
 }
+// The margin m for a motion of magnitude fm (max |theta_i|, or max |F_c| at the event's source pixel) and dtfac = max(period, 1)
+// max(1, |d|, |1 - d|): an event is a candidate when a + 1e-6 or b + 1e-6 lies in [0, m) or (1 - m, 1).  The fp32 displacement
+// dx = fl(rx -/+ dt32 f), dt32 = fl(fl(tau32 - d32) period32), is off by at most 7 * 2^-24 fm dtfac: the roundings of tau (2^-25
+// absolute), of d and of the difference, of the period and of the product (2^-24 relative each), of theta (2-DoF), of the fma and of the
+// `+ 1e-6`; fractional sources add the rounding of rx (2^-25) and the fma's on a sum of magnitude up to 1.  All of it is relative to
+// fm dtfac otherwise: a zero motion -- the optimiser's usual starting point, where every event sits ON a border -- has no candidates.
+template <bool FRAC>
+__device__ __forceinline__ float exact_margin(float fm, float dtfac) { return fmaf(0x1.4p-21f * fm, dtfac, FRAC ? 0x1p-22f : 0.f); }
 
 __device__ __forceinline__ float time_scale(const WarpParams &wp) {
     return wp.normalize ? 1.0f : (float)(wp.tmm[1] - wp.tmm[0]);
@@ -496,12 +515,38 @@ __device__ __forceinline__ int segment_of_block(int nseg, unsigned bx = blockIdx
 #endif
 }
 
+// Row stride of an LDS window of width w.  With a power-of-two stride (the first version: a shift per index) the bank of a
+// cell is its COLUMN modulo 32 whatever its row -- a 20-pixel-wide window used 20 of the 32 banks, and the two rows of a
+// 2 x 2 footprint always collided (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.55-0.70 in K1 and K3, profiles/r02_sq_*).  An odd
+// stride walks the banks row by row; the index costs one v_mad_u32_u24 instead of a shift + add.
+__host__ __device__ inline int window_stride(int w) { return (w < 15 ? 15 : w) | 1; }
+
 struct Window {
     int r0, c0, h, w;  // top-left corner in the padded image, extent (clipped to the image and to LDS)
     int stride;        // LDS row stride in words: odd (window_stride), so that the rows of a window start in different banks
     bool clipped;      // the bounding box did not fit: votes / reads outside the window but inside the image exist
-    bool border;       // 2-DoF: the segment holds an event within fp32 rounding of a cell border (K1's verdict, re-used by K3)
+    bool border;       // the segment holds an event within fp32 rounding of a cell border (K1's verdict, re-used by K3)
+    unsigned long long bmask;  // ... and where: bit q = such an event among the segment's slots [q * kSlots / 64, (q + 1) * kSlots / 64)
 };
+// A window as K1 publishes it for K3 of the same evaluation (RefArgs::win): position | geometry + flags | the 64 bits of bmask
+// (the LDS row stride follows from the width)
+__device__ __forceinline__ int4 pack_window(const Window &w) {
+    return make_int4((int)(((unsigned)(w.r0 + 16384) << 16) | (unsigned)(w.c0 + 16384)),
+                     w.h | (w.w << 12) | (w.clipped ? (1 << 28) : 0) | (w.border ? (1 << 29) : 0),
+                     (int)(unsigned)w.bmask, (int)(unsigned)(w.bmask >> 32));
+}
+__device__ __forceinline__ Window unpack_window(int4 kw) {
+    Window w;
+    w.r0 = (int)((unsigned)kw.x >> 16) - 16384;
+    w.c0 = (int)((unsigned)kw.x & 0xFFFFu) - 16384;
+    w.h = kw.y & 0xFFF;
+    w.w = (kw.y >> 12) & 0xFF;
+    w.stride = window_stride(w.w);
+    w.clipped = ((kw.y >> 28) & 1) != 0;
+    w.border = ((kw.y >> 29) & 1) != 0;
+    w.bmask = (unsigned long long)(unsigned)kw.z | ((unsigned long long)(unsigned)kw.w << 32);
+    return w;
+}
 // how K3 obtains dL/dIWE: from a materialised G image; folded G = c2 (IWE - mu) with the statistics K2 left in
 // `stat`; or (2-DoF) deferred -- K3 gathers the raw image and the image statistics itself, the chain factors are
 // applied by k_finish_deferred, and K2 is not launched at all
@@ -510,11 +555,6 @@ struct Window {
 // VALU-bound on the large configurations: SQ_ACTIVE_INST_VALU x 8 waves ~ 0.8 of the SIMD cycles in K1 / K3 of cfg3).
 __device__ __forceinline__ int pix_index(int r, int c, int W) { return (int)__umul24((unsigned)r, (unsigned)W & 0xFFFFFFu) + c; }
 
-// Row stride of an LDS window of width w.  With a power-of-two stride (the first version: a shift per index) the bank of a
-// cell is its COLUMN modulo 32 whatever its row -- a 20-pixel-wide window used 20 of the 32 banks, and the two rows of a
-// 2 x 2 footprint always collided (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.55-0.70 in K1 and K3, profiles/r02_sq_*).  An odd
-// stride walks the banks row by row; the index costs one v_mad_u32_u24 instead of a shift + add.
-__host__ __device__ inline int window_stride(int w) { return (w < 15 ? 15 : w) | 1; }
 
 constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3;  // kFoldScale: G image stored without its chain factor
 // kFoldStatsInside: kFoldStats for a plain (not normalised) variance whose K2 runs INSIDE the K3 launch -- the first
@@ -1846,7 +1886,7 @@ static EvView ev_view(const cmax_handle_s *h) {
     ev.ev = h->evp;
     ev.rx = h->rx;
     ev.ry = h->ry;
-    ev.n = h->n;
+    ev.tau64 = h->tau64;
     return ev;
 }
 
@@ -1881,6 +1921,7 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
     ra.raw_zero = raw_lines;  // (the deferred objective resets its sums through ra.stat instead: raw_reset)
     if (publish_windows && h->n > 0) {  // K3 of the same evaluation re-uses the LDS windows (see objective_finish)
         ra.win = h->d_win;
+        ra.shifts = h->d_shifts;
         h->win_motion = motion;
         h->win_model = model;
         h->win_nref = n_ref;
@@ -2216,8 +2257,11 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         dev_free(&h->d_segs);
         dev_free(&h->d_gpart);
         dev_free(&h->d_win);
+    dev_free(&h->d_shifts);
+        dev_free(&h->d_shifts);
         int rc = dev_alloc(h, &h->d_segs, h->nseg);
         if (!rc) rc = dev_alloc(h, &h->d_win, (int64_t)4 * h->nseg);
+        if (!rc) rc = dev_alloc(h, &h->d_shifts, (int64_t)4 * h->nseg * kShiftWordsMax);
         if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 2);
         if (rc) return rc;
         h->seg_cap = h->nseg;
@@ -2552,6 +2596,25 @@ static bool owned_groups_apply(const cmax_handle_s *h, const cmax_objective_t *d
 
 // votes of every reference time (+ the un-warped image when needed) into images[0 .. n_images);
 // zero_mask bit k: images[k] is already zero (the handle's double-buffered images)
+// K1 without its votes: the LDS windows and the fp64 cell decisions (RefArgs::win / shifts) of this warp, for a K3 that follows
+static int publish_windows(cmax_handle_s *h, const cmax_objective_t *d, const float *motion, hipStream_t s) {
+    RefArgs ra = {};
+    ra.win = h->d_win;
+    ra.shifts = h->d_shifts;
+    ra.windows_only = 1;
+    for (int k = 0; k < d->n_ref; ++k) ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+    const EvView ev = ev_view(h);
+    const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
+    switch (d->model) {
+        case CMAX_MODEL_2DOF: launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, ra, d->n_ref, s); break;
+        case CMAX_MODEL_DENSE: launch_vote<CMAX_MODEL_DENSE>(h, ev, wp, ra, d->n_ref, s); break;
+        default: launch_vote<CMAX_MODEL_VOXEL>(h, ev, wp, ra, d->n_ref, s); break;
+    }
+    CMAX_CHECK_LAUNCH();
+    h->win_motion = nullptr;  // (nobody may take these windows for those of a vote)
+    return 0;
+}
+
 static int objective_vote(cmax_handle_t h, const cmax_objective_t *d, const float *motion, float *images, unsigned zero_mask,
                           int *n_images_out, hipStream_t s, bool want_mu = false, double *raw_reset = nullptr, double *raw_lines = nullptr) {
     const int64_t npix = (int64_t)h->Hp * h->Wp;
@@ -2790,7 +2853,14 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         ra.zero[k] = (deferred || stats_inside) ? ia.zero[k] : nullptr;
         same_vote = same_vote && h->win_d[k] == ra.d[k];
     }
-    ra.win = same_vote ? h->d_win : nullptr;  // the windows K1 derived for exactly this warp
+    // K3 follows the windows -- and the fp64 cell decisions -- of a K1 launch with exactly this warp: that of the same evaluation, or
+    // (the stand-alone cmax_objective_finish, whose vote the handle cannot vouch for) a K1 launch that only publishes them
+    if (!same_vote && grad && h->n > 0) {
+        rc = publish_windows(h, d, motion, s);
+        if (rc) return rc;
+    }
+    ra.win = h->d_win;
+    ra.shifts = h->d_shifts;
     ra.n_events = h->n;
     if (stats_inside) {
         // two sweeps of 4 pixels per thread (cfg5, K3 with 1 / 2 / 4 / 8 sweeps: 18.8 / 17.9 / 18.3 / 18.3 us; tuning: CMAX_STAT_SWEEPS)
@@ -2832,7 +2902,8 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             const int tr0 = (int)((int64_t)h->ntr * b / bands), tr1 = (int)((int64_t)h->ntr * (b + 1) / bands);
             const int s0 = h->row_seg_start[tr0], s1 = h->row_seg_start[tr1];
             RefArgs rb = ra;
-            if (rb.win) rb.win += s0;  // (one reference time: the windows of segment i sit at win[i])
+            rb.win += s0;  // (one reference time: the windows of segment i sit at win[i])
+            rb.shifts += (int64_t)s0 * (h->big ? 512 : 256);
             if (s1 > s0) launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, rb, d->n_ref, fold, op, nullptr, (float *)grad, b == 0 ? res : nullptr, owned, s, s0, s1 - s0);
             CMAX_CHECK_LAUNCH();
             CMAX_CHECK_HIP(hipEventRecord(h->band_ev[b], s));

@@ -7,12 +7,12 @@ events (cfg5) -- plus the cuts no BASELINE configuration reaches (test_work_list
 loss and gradient with oracle/cmax_oracle.c (scalar C, ~6e7 events/s: seconds per case).
 
 Tolerance (BASELINE north_star): 1e-4 relative, fp32 device path against the fp64 oracle -- for the IWE, the loss and
-the gradient.  One refinement for the gradient, explained and computed in tests/_border.py: the handful of events whose
-warped coordinate lies within fp32 rounding of a bilinear cell border take their derivative from the neighbouring cell
-in any fp32 evaluation (the objective's gradient is discontinuous there); their possible contribution is bounded in
-fp64 from the oracle's own intermediates and added to the gate, element-wise:  |g - g_ref| <= 1e-4 max|g_ref| + bound.
-The 2-DoF gradient (ONE sum over all events, so such a bound is not local) is held to the PLAIN gate: since round 3 the
-kernels decide the cell of an event that lies within fp32 rounding of a border in fp64 (warp_one), like the reference."""
+the gradient, with NO slack: |g - g_ref| <= 1e-4 max|g_ref| for every entry of every gradient (round 4).  The handful of
+events whose warped coordinate lies within fp32 rounding of a bilinear cell border (the objective's gradient is discontinuous
+there: tests/_border.py counts them) are warped again in fp64 by the kernels (warp_exact: 2-DoF since round 3, dense and voxel
+since round 4), so they take their derivative from the cell the reference's fp64 arithmetic puts them in.  The oracle is
+evaluated on the motion THE DEVICE HOLDS: the flow / voxel rounded to fp32 (the boundary hands the library fp32 flow fields;
+the reference itself computes in the dtype of its inputs), a 2-DoF theta in fp64 (cmax_objective_t::motion_dtype)."""
 import numpy as np
 import pytest
 import torch
@@ -27,13 +27,18 @@ from _border import ambiguity_bound, raw_image_grad  # noqa: E402
 TOL = 1e-4
 
 
+def f32(x):
+    """the motion as the device holds it: rounded to fp32 (values), fp64 (container) for the oracle"""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
 def rel_max(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
 def check(tag, h, res, grad, ref, bound=None, n_amb=0):
-    """bound: element-wise slack for cell-border events (tests/_border.py), or None for the plain 1e-4 gate."""
+    """The plain 1e-4 gate (bound = None: every caller since round 4).  n_amb: cell-border events of the batch, for the log."""
     e_iwe = rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"])
     e_loss = abs(res[0].item() - ref["loss"]) / abs(ref["loss"])
     g = grad.double().cpu().numpy()
@@ -46,7 +51,7 @@ def check(tag, h, res, grad, ref, bound=None, n_amb=0):
     print(f"[fullsize] {tag}: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e} | gated {e_gate:.2e} "
           f"({n_over} of {err.size} gradient entries above 1e-4, {n_amb} cell-border events)")
     assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL, (tag, e_iwe, e_loss, e_grad, e_gate)
-    assert n_over <= 2 * max(n_amb, 0), (tag, n_over, n_amb)  # every entry above the gate belongs to a border event
+    assert n_over == 0 or bound is not None, (tag, n_over)
 
 
 def test_cfg2_full_size_bench_workload(golden):
@@ -86,9 +91,9 @@ def test_cfg3_full_size_dense_gradmag():
     flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
     h = E.CMaxHandle(size).set_events(ev)
     res, grad = h.evaluate(E.make_descriptor("gradient_magnitude", "dense-flow"), flow)
-    ref = orc.objective(ev, flow, "dense-flow", size, cost="gradient_magnitude", sigma=0)
-    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
-    check("cfg3 5M 480x640 dense grad-mag", h, res, grad, ref, bound, n_amb)
+    ref = orc.objective(ev, f32(flow), "dense-flow", size, cost="gradient_magnitude", sigma=0)
+    _, n_amb = ambiguity_bound(ev, f32(flow), "dense-flow", size, raw_image_grad(ref, 0))
+    check("cfg3 5M 480x640 dense grad-mag", h, res, grad, ref, None, n_amb)
 
 
 def test_cfg4_full_size_burgers_voxel():
@@ -99,9 +104,9 @@ def test_cfg4_full_size_burgers_voxel():
     voxel = orc.construct_dense_flow_voxel(f0 / 20.0, Tn, "burgers", "middle") * 20.0
     h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
     res, grad = h.evaluate(E.make_descriptor("image_variance", "dense-flow-voxel", sigma=1.0, time_bin=Tn), voxel)
-    ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=1)
-    bound, n_amb = ambiguity_bound(ev, voxel, "dense-flow-voxel", size, raw_image_grad(ref, 1))
-    check("cfg4 2M 260x346 voxel T=10 sigma 1", h, res, grad, ref, bound, n_amb)
+    ref = orc.objective(ev, f32(voxel), "dense-flow-voxel", size, cost="image_variance", sigma=1)
+    _, n_amb = ambiguity_bound(ev, f32(voxel), "dense-flow-voxel", size, raw_image_grad(ref, 1))
+    check("cfg4 2M 260x346 voxel T=10 sigma 1", h, res, grad, ref, None, n_amb)
 
 
 def test_cfg4_size_voxel_plain_variance():
@@ -114,11 +119,11 @@ def test_cfg4_size_voxel_plain_variance():
     h = E.CMaxHandle(size).set_events(ev, time_bin=Tn)
     assert h.batch_info()["owned_groups"]
     desc = E.make_descriptor("image_variance", "dense-flow-voxel", sigma=0.0, time_bin=Tn)
-    ref = orc.objective(ev, voxel, "dense-flow-voxel", size, cost="image_variance", sigma=0)
-    bound, n_amb = ambiguity_bound(ev, voxel, "dense-flow-voxel", size, raw_image_grad(ref, 0))
+    ref = orc.objective(ev, f32(voxel), "dense-flow-voxel", size, cost="image_variance", sigma=0)
+    _, n_amb = ambiguity_bound(ev, f32(voxel), "dense-flow-voxel", size, raw_image_grad(ref, 0))
     for rep in range(2):
         res, grad = h.evaluate(desc, voxel)
-        check(f"cfg4-size 2M voxel T=10 plain variance #{rep}", h, res, grad, ref, bound, n_amb)
+        check(f"cfg4-size 2M voxel T=10 plain variance #{rep}", h, res, grad, ref, None, n_amb)
 
 
 def test_cfg5_shard_full_size_with_gradient():
@@ -128,9 +133,9 @@ def test_cfg5_shard_full_size_with_gradient():
     flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
     h = E.CMaxHandle(size).set_events(ev)
     res, grad = h.evaluate(E.make_descriptor("image_variance", "dense-flow"), flow)
-    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
-    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
-    check("cfg5 shard 2.5M 720x1280 dense variance", h, res, grad, ref, bound, n_amb)
+    ref = orc.objective(ev, f32(flow), "dense-flow", size, cost="image_variance", sigma=0)
+    _, n_amb = ambiguity_bound(ev, f32(flow), "dense-flow", size, raw_image_grad(ref, 0))
+    check("cfg5 shard 2.5M 720x1280 dense variance", h, res, grad, ref, None, n_amb)
 
 
 WORK_LISTS = [
@@ -159,10 +164,10 @@ def test_work_list_variants_against_the_oracle(tag, size, n, Tn, model, seg_even
     assert (info["segments"] > 1024) == wide, (tag, info)
     assert h.batch_info()["owned_groups"]
     desc = E.make_descriptor("image_variance", model, sigma=0.0, time_bin=Tn)
-    ref = orc.objective(ev, motion, model, size, cost="image_variance", sigma=0)
-    bound, n_amb = ambiguity_bound(ev, motion, model, size, raw_image_grad(ref, 0))
+    ref = orc.objective(ev, f32(motion), model, size, cost="image_variance", sigma=0)
+    _, n_amb = ambiguity_bound(ev, f32(motion), model, size, raw_image_grad(ref, 0))
     res, grad = h.evaluate(desc, motion)
-    check(tag, h, res, grad, ref, bound, n_amb)
+    check(tag, h, res, grad, ref, None, n_amb)
 
 
 def test_work_list_rule_on_the_bench_configurations():
@@ -187,17 +192,15 @@ def test_cfg5_two_time_slices_of_5m_against_the_oracle():
     ranks = [E.CMaxHandle(size).set_events(ev[: n // 2], tmin, tmax), E.CMaxHandle(size).set_events(ev[n // 2:], tmin, tmax)]
     images = sum(h.objective_vote(desc, flow) for h in ranks)
     outs = [h.objective_finish(desc, flow, images) for h in ranks]
-    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
+    ref = orc.objective(ev, f32(flow), "dense-flow", size, cost="image_variance", sigma=0)
     gsum = sum(g.double() for _, g in outs).cpu().numpy()
     e_iwe = rel_max(images[0].cpu().numpy(), ref["iwes"]["iwe"])
     e_loss = abs(outs[0][0][0].item() - ref["loss"]) / abs(ref["loss"])
-    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    _, n_amb = ambiguity_bound(ev, f32(flow), "dense-flow", size, raw_image_grad(ref, 0))
     gmax = np.abs(ref["grad"]).max()
     e_grad = rel_max(gsum, ref["grad"])
-    e_gate = (np.abs(gsum - ref["grad"]) - 1.01 * bound).max() / gmax
-    print(f"[fullsize] cfg5 2 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e} | gated {e_gate:.2e} "
-          f"({n_amb} cell-border events)")
-    assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL
+    print(f"[fullsize] cfg5 2 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {e_grad:.2e} ({n_amb} cell-border events)")
+    assert e_iwe <= TOL and e_loss <= TOL and e_grad <= TOL
 
 
 def test_cfg5_full_20m_eight_slices():
@@ -210,8 +213,8 @@ def test_cfg5_full_20m_eight_slices():
     ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
     flow = E.utils.generate_smooth_flow(size, 20, seed=1046)
     desc = E.make_descriptor("image_variance", "dense-flow")
-    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
-    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    ref = orc.objective(ev, f32(flow), "dense-flow", size, cost="image_variance", sigma=0)
+    _, n_amb = ambiguity_bound(ev, f32(flow), "dense-flow", size, raw_image_grad(ref, 0))
     gmax = np.abs(ref["grad"]).max()
     tmin, tmax = ev[:, 2].min(), ev[:, 2].max()
     from event_based_optical_flow_amd.distributed import time_slice_bounds
@@ -227,12 +230,10 @@ def test_cfg5_full_20m_eight_slices():
     e_iwe = rel_max(images[0].cpu().numpy(), ref["iwes"]["iwe"])
     e_loss = max(abs(o[0][0].item() - ref["loss"]) / abs(ref["loss"]) for o in outs)
     err = np.abs(gsum - ref["grad"])
-    e_gate = (err - 1.01 * bound).max() / gmax
     n_over = int((err > TOL * gmax).sum())
-    print(f"[fullsize] cfg5 20M = 8 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {err.max() / gmax:.2e} | gated {e_gate:.2e} "
+    print(f"[fullsize] cfg5 20M = 8 x 2.5M time slices: rel err iwe {e_iwe:.2e} loss {e_loss:.2e} grad {err.max() / gmax:.2e} "
           f"({n_over} of {err.size} gradient entries above 1e-4, {n_amb} cell-border events)")
-    assert e_iwe <= TOL and e_loss <= TOL and e_gate <= TOL
-    assert n_over <= 2 * n_amb
+    assert e_iwe <= TOL and e_loss <= TOL and err.max() <= TOL * gmax
     for h in ranks:
         h.close()
     del ranks, images, outs
@@ -240,7 +241,7 @@ def test_cfg5_full_20m_eight_slices():
     h = E.CMaxHandle(size).set_events(torch.from_numpy(ev).cuda())
     assert h.n_events == n
     res, grad = h.evaluate(desc, flow)
-    check("cfg5 20M 720x1280 dense variance, one handle", h, res, grad, ref, bound, n_amb)
+    check("cfg5 20M 720x1280 dense variance, one handle", h, res, grad, ref, None, n_amb)
     h.close()
 
 
@@ -261,8 +262,8 @@ def test_mean_from_votes_along_the_border(model, sigma, omit):
     h = E.CMaxHandle(size).set_events(ev, time_bin=tb) if tb else E.CMaxHandle(size).set_events(ev)
     assert h.batch_info()["owned_groups"]
     desc = E.make_descriptor("image_variance", model, sigma=float(sigma), omit_boundary=omit, time_bin=tb)
-    ref = orc.objective(ev, motion, model, size, cost="image_variance", sigma=sigma, omit_boundary=omit)
-    bound, n_amb = ambiguity_bound(ev, motion, model, size, raw_image_grad(ref, sigma))
+    ref = orc.objective(ev, f32(motion), model, size, cost="image_variance", sigma=sigma, omit_boundary=omit)
+    _, n_amb = ambiguity_bound(ev, f32(motion), model, size, raw_image_grad(ref, sigma))
     for rep in range(3):  # the vote sums are double-buffered across evaluations: every one must see clean accumulators
         res, grad = h.evaluate(desc, motion)
-        check(f"border {model} sigma {sigma} omit {int(omit)} #{rep}", h, res, grad, ref, bound, n_amb)
+        check(f"border {model} sigma {sigma} omit {int(omit)} #{rep}", h, res, grad, ref, None, n_amb)
