@@ -73,7 +73,9 @@ struct EvView {
     const uint2 *ev;      // .x = row | col << 12 | bin << 24 ; .y = bits of fp32 tau = (t - tmin) / (tmax - tmin)
     const float *rx;      // fractional residual of the source coordinate (nullptr if integral)
     const float *ry;
-    const double *tau64;  // normalised time in fp64, same order as `ev`: read only for the few events whose cell is decided in fp64 (warp_exact)
+    const double *tau64;  // BINNED handles (the packed word's top byte holds the voxel bin): normalised time in fp64, same order as `ev` --
+                          // read only for the few events whose cell is decided in fp64 (warp_exact); null on un-binned handles, whose
+                          // packed word carries the time's residual beyond fp32 (tau_refined)
 };
 
 struct WarpParams {
@@ -490,14 +492,21 @@ __device__ __forceinline__ Warped warp_exact(const EvView &ev, unsigned ex, int6
     w.f1 = 0.f;
     return w;
 }
-// The margin m for a motion of magnitude fm (max |theta_i|, or max |F_c| at the event's source pixel) and dtfac = max(period, 1)
-// max(1, |d|, |1 - d|): an event is a candidate when a + 1e-6 or b + 1e-6 lies in [0, m) or (1 - m, 1).  The fp32 displacement
-// dx = fl(rx -/+ dt32 f), dt32 = fl(fl(tau32 - d32) period32), is off by at most 7 * 2^-24 fm dtfac: the roundings of tau (2^-25
-// absolute), of d and of the difference, of the period and of the product (2^-24 relative each), of theta (2-DoF), of the fma and of the
-// `+ 1e-6`; fractional sources add the rounding of rx (2^-25) and the fma's on a sum of magnitude up to 1.  All of it is relative to
-// fm dtfac otherwise: a zero motion -- the optimiser's usual starting point, where every event sits ON a border -- has no candidates.
+// The margin m of an event: it is a candidate for warp_exact when a + 1e-6 or b + 1e-6 lies in [0, m) or (1 - m, 1).  With eps = 2^-24
+// the fp32 displacement dx = fl(rx -/+ dt32 f), dt32 = fl(fl(tau32 - d32) period32), is off by at most
+//   eps (3.5 |dt f| + kappa |f|),   kappa = 0 for the reference time "first" (d = 0: the rounding of tau is then relative to dt itself),
+//                                   else (1 + |d| / 2) period (roundings of tau and d: absolute in dt, so they scale with |f| alone)
+// -- 3.5: the subtraction, the period, the product, the fma and the `+ 1e-6` at eps / 2 each, tau at eps (d = 0), theta at eps / 2
+// (2-DoF) -- and |dt| <= period max(|d|, |1 - d|).  m = 1.5 eps (4 period max(|d|, |1 - d|) + kappa) fm with fm = max |motion component|
+// of the event (a function of the EVENT alone, so that nothing depends on how threads and events are matched).  Fractional sources add
+// the rounding of rx and the fma's on a sum of magnitude up to 1.  Everything else is RELATIVE to the motion: a zero motion -- the
+// optimiser's usual starting point, where every event sits ON a border -- has no candidates.
+__device__ __forceinline__ float exact_margin_coef(float d, float tscale) {
+    const float kappa = d == 0.f ? 0.f : (1.f + 0.5f * fabsf(d)) * tscale;
+    return 0x1.8p-24f * (4.f * tscale * fmaxf(fabsf(d), fabsf(1.f - d)) + kappa);
+}
 template <bool FRAC>
-__device__ __forceinline__ float exact_margin(float fm, float dtfac) { return fmaf(0x1.4p-21f * fm, dtfac, FRAC ? 0x1p-22f : 0.f); }
+__device__ __forceinline__ float exact_margin(float coef, float fm) { return fmaf(coef, fm, FRAC ? 0x1p-21f : 0.f); }
 
 __device__ __forceinline__ float time_scale(const WarpParams &wp) {
     return wp.normalize ? 1.0f : (float)(wp.tmm[1] - wp.tmm[0]);
@@ -1886,7 +1895,7 @@ static EvView ev_view(const cmax_handle_s *h) {
     ev.ev = h->evp;
     ev.rx = h->rx;
     ev.ry = h->ry;
-    ev.tau64 = h->tau64;
+    ev.tau64 = h->n_time_bin > 0 ? h->tau64 : nullptr;
     return ev;
 }
 

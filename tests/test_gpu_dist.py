@@ -272,7 +272,7 @@ def test_gradient_exchange_in_row_bands(world1_nccl, cost, sigma):
     desc = E.make_descriptor(cost, "dense-flow", sigma=sigma)
     h.comm_init(force_rccl=True)
     res1, grad1 = h.evaluate_dist(desc, flow)
-    ref = orc.objective(ev, flow, "dense-flow", size, cost=cost, sigma=int(sigma))
+    ref = orc.objective(ev, np.asarray(flow, dtype=np.float32).astype(np.float64), "dense-flow", size, cost=cost, sigma=int(sigma))  # the flow the device holds
     for bands in (2, 5, 64):
         h.comm_set_c2_bands(bands)
         for _ in range(2):
@@ -281,8 +281,7 @@ def test_gradient_exchange_in_row_bands(world1_nccl, cost, sigma):
         assert abs(res_b[0].item() - res1[0].item()) <= 1e-6 * abs(res1[0].item())
         assert rel_max(grad_b.cpu().numpy(), grad1.cpu().numpy()) <= 2e-6, bands
         assert abs(res_b[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
-        err = np.abs(grad_b.double().cpu().numpy() - ref["grad"])
-        assert (err > TOL * np.abs(ref["grad"]).max()).sum() <= 4  # (cell-border events of a 700k-event batch: tests/_border.py)
+        assert rel_max(grad_b.double().cpu().numpy(), ref["grad"]) <= TOL  # (plain gate: cell-border events are decided in fp64, round 4)
     h.comm_set_c2_bands(1)
     with pytest.raises(E._lib.CmaxError):
         h.comm_set_c2_bands(0)
@@ -293,9 +292,7 @@ def test_cfg5_half_batch_through_the_communicator_path(world1_nccl):
     """What rank 0 of `bench.py --gpus 2` runs for cfg5 (also.cfg5_strong): a 10M-event time slice at 1280x720 -- BIG segments
     (>= 8M events: b512 kernels) on an owned work list -- through cmax_objective_dist under a real (1-rank) RCCL communicator:
     K1 -> all-reduce -> k_stats -> K3 (kFoldStats, owned, stores) -> all-reduce, also with the gradient exchanged in row bands.
-    Against the oracle on the same 10M events, with the per-pixel cell-border bound of tests/_border.py."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _border import ambiguity_bound, raw_image_grad
+    Against the oracle on the same 10M events (and the flow rounded to fp32, as the device holds it) at the plain 1e-4 gate."""
 
     size, n = (720, 1280), 10_000_000
     ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.025, seed=46)
@@ -305,8 +302,7 @@ def test_cfg5_half_batch_through_the_communicator_path(world1_nccl):
     assert h.batch_info()["owned_groups"]
     desc = E.make_descriptor("image_variance", "dense-flow")
     h.comm_init(force_rccl=True)
-    ref = orc.objective(ev, flow, "dense-flow", size, cost="image_variance", sigma=0)
-    bound, n_amb = ambiguity_bound(ev, flow, "dense-flow", size, raw_image_grad(ref, 0))
+    ref = orc.objective(ev, np.asarray(flow, dtype=np.float32).astype(np.float64), "dense-flow", size, cost="image_variance", sigma=0)
     gmax = np.abs(ref["grad"]).max()
     for bands in (1, 3):
         h.comm_set_c2_bands(bands)
@@ -314,7 +310,7 @@ def test_cfg5_half_batch_through_the_communicator_path(world1_nccl):
             res, grad = h.evaluate_dist(desc, flow)
         torch.cuda.synchronize()
         err = np.abs(grad.double().cpu().numpy() - ref["grad"])
-        e_gate = (err - 1.01 * bound).max() / gmax
-        print(f"[dist 10M] bands {bands}: loss rel err {abs(res[0].item() - ref['loss']) / abs(ref['loss']):.2e}, grad gated {e_gate:.2e} ({n_amb} cell-border events)")
+        e_gate = err.max() / gmax
+        print(f"[dist 10M] bands {bands}: loss rel err {abs(res[0].item() - ref['loss']) / abs(ref['loss']):.2e}, grad {e_gate:.2e}")
         assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"]) and e_gate <= TOL
     h.comm_destroy()

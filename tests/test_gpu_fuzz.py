@@ -48,6 +48,8 @@ def draw_case(seed):
 def test_random_configuration_against_oracle(seed):
     c = draw_case(seed)
     size = (c["H"], c["W"])
+    if c["model"] != "2d-translation":  # the flow as the device holds it: rounded to fp32 (a 2-DoF theta crosses the ABI in fp64)
+        c["motion"] = np.asarray(c["motion"], dtype=np.float32).astype(np.float64)
     ref = orc.objective(c["ev"], c["motion"], c["model"], size, cost=c["cost"], sigma=c["sigma"], outer_padding=c["pad"])
     h = E.CMaxHandle(size, c["pad"]).set_events(c["ev"], time_bin=c["T"])
     obj = E.ContrastObjective(h, c["model"], cost=c["cost"], sigma=c["sigma"])
@@ -68,15 +70,16 @@ def test_random_configuration_against_oracle(seed):
         frac = np.mod(w[:, :2] + 1e-6, 1.0)
         if np.isfinite(frac).all():
             n_border += int((np.minimum(frac, 1.0 - frac) < 3e-5).sum())
-    # (round 3: a 2-DoF theta crosses the ABI in fp64 here and events on a cell border are re-warped in fp64 -- the plain gate holds
-    # for integral source coordinates; fractional ones are stored as fp32 residuals, which can still flip a cell)
-    if n_border and not (c["model"] == "2d-translation" and not c["frac"]):
+    # (events on a cell border are re-warped in fp64 -- 2-DoF: round 3, with its theta crossing the ABI in fp64; dense / voxel: round 4,
+    # against the oracle on the fp32-rounded flow -- so the plain gate holds for integral source coordinates; fractional ones are
+    # stored as fp32 residuals, which can still flip a cell)
+    if n_border and c["frac"]:
         tol = 2e-2
     assert abs(loss.item() - ref["loss"]) <= tol * max(abs(ref["loss"]), 1e-12), (info, loss.item(), ref["loss"])
     gmax = np.abs(ref["grad"]).max()
     if gmax > 0:
         err = np.abs(g - ref["grad"])
-        if n_border and c["model"] != "2d-translation":
+        if n_border and c["frac"] and c["model"] != "2d-translation":
             # per-pixel gradients: an event ON a cell border leaves the image unchanged but takes its derivative from the
             # neighbouring cell -- its own flow-gradient pixel (x, y channel, per reference time) differs by one event's term
             assert (err > 1e-4 * gmax).sum() <= 6 * n_border and err.max() <= gmax, (info, n_border, err.max(), gmax)
