@@ -7,14 +7,17 @@ analytic gradient (BASELINE.json metric), on synthetic events already resident i
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): BASELINE configs[1] = cfg2 = 1M synthetic events, 346x260 (H=260, W=346), 2-DoF
-translational flow, image-variance cost + analytic gradient.  One evaluation = K1 (warp + vote) + K3 (gather + gradient); on
-one GPU it is timed in its RAW form (config.result_form): K3 leaves 32 x 6 partial sums on the device and the consumer
-folds them on the host when it reads the result (cmax_objective_raw + cmax_finalize_raw_host) -- here once per run, exactly
-as a device-resident result was read once per run before.  `also` carries the other forms (cfg2_device_result =
-cmax_objective with its finishing launch; cfg2_host_result = cmax_objective_host, every evaluation delivered to the host
-before the next starts), the headline with blur and on a sharp image, the other single-GPU configurations (cfg3, cfg4, a
-cfg5 shard), cfg5 AS BASELINE STATES IT on one GPU (cfg5_strong: 20M events, the N = 1 point of its strong-scaling curve)
-and `hbm`: 64M events, a packed stream larger than the 256 MiB Infinity Cache.  For N > 1 every rank owns one 1M-event time
+translational flow, image-variance cost + analytic gradient.  `value` times the COMPLETE evaluation: cmax_objective = K1
+(warp + vote) + K3 (gather + gradient) + the one-wave finishing kernel, loss and gradient left on the device
+(config.result_form; round 3 timed the raw form -- VERDICT r3 / ADVICE r3).  `also` carries the other forms (cfg2_raw =
+cmax_objective_raw: K1 + K3, 32 x 6 partial sums folded by the consumer; cfg2_host_result = cmax_objective_host, every
+evaluation delivered to the host before the next starts -- their fractions are repeated in roofline.frac_raw_form /
+frac_host_result), the headline with blur, on a sharp image and at a motion of 80 px (cfg2_theta80), the other single-GPU
+configurations (cfg3, cfg4, a cfg5 shard) -- cfg3 and the cfg5 shard also with the per-pixel random flow of
+src/utils/flow_utils.py:20-30 (cfg3_rough, cfg5_rough: the unfriendly case for coalesced gathers and LDS windows) -- cfg5 AS
+BASELINE STATES IT on one GPU (cfg5_strong: 20M events, the N = 1 point of its strong-scaling curve) and `hbm`: 64M events,
+a packed stream larger than the 256 MiB Infinity Cache.  roofline.launch_floor_us = two dependent EMPTY launches with the
+evaluation's grids, measured in the same run.  For N > 1 every rank owns one 1M-event time
 slice of an N x 1M-event batch (weak scaling); both all-reduces of an evaluation (IWE, gradient) are enqueued by
 libcmax_hip.so itself (RCCL, cmax_objective_dist), and `also.cfg5_strong` is cfg5 split into N time slices.
 
@@ -68,8 +71,15 @@ WORKLOADS = {
     # what an optimiser converges to; the friendliest case for LDS / L2 atomics is the uniform stream above)
     # the headline's other two forms (see run_workload): results left ON THE DEVICE by a finishing kernel (cmax_objective), and
     # results delivered TO THE HOST after every evaluation (cmax_objective_host: what a sequential optimiser sees)
-    "cfg2_device_result": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="device",
-                               desc="cfg2 through cmax_objective: loss + gradient finished on the device (K1, K3, k_finish_raw)"),
+    "cfg2_raw": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="raw",
+                     desc="cfg2 through cmax_objective_raw: K1 + K3, 32 x 6 partial sums left on the device and folded by the consumer"),
+    "cfg2_theta80": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, theta=(80.0, -50.0),
+                         desc="cfg2 at a large motion: theta = (80, -50) px over the batch (windows of the source tiles' size + 80 x 50 px)"),
+    # "dense F ~ U(-5, 5) per pixel *and* a smooth field" -- the per-pixel random flow of src/utils/flow_utils.py:20-30
+    "cfg3_rough": dict(H=480, W=640, n=5_000_000, model="dense-flow", cost="gradient_magnitude", sigma=0.0, rough=5.0,
+                       desc="cfg3 with a per-pixel random flow F ~ U(-5, 5): 5M events, 640x480, dense flow, gradient_magnitude"),
+    "cfg5_rough": dict(H=720, W=1280, n=2_500_000, model="dense-flow", cost="image_variance", sigma=0.0, rough=5.0,
+                       desc="cfg5 shard with a per-pixel random flow F ~ U(-5, 5): 2.5M events, 1280x720, dense flow, image_variance"),
     "cfg2_host_result": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="host",
                              desc="cfg2 through cmax_objective_host: every evaluation returns loss + gradient to the host before the next starts"),
     "cfg2_sigma1": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=1.0,
@@ -146,7 +156,9 @@ def make_inputs(cfg, rank, world, seed=46, structured=False):
         ev = E.utils.generate_events(n, H, W, tmin=t0, tmax=t1, seed=seed + rank)
     T = 0
     if cfg["model"] == "2d-translation":
-        motion = np.array([12.3, -7.7])
+        motion = np.array(cfg.get("theta", (12.3, -7.7)), dtype=np.float64)
+    elif cfg["model"] == "dense-flow" and cfg.get("rough"):
+        motion = E.utils.generate_dense_optical_flow((H, W), cfg["rough"], seed=seed + 1000)  # per pixel, src/utils/flow_utils.py:20-30
     elif cfg["model"] == "dense-flow":
         motion = E.utils.generate_smooth_flow((H, W), 20, seed=seed + 1000)
     else:
@@ -307,14 +319,13 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     # one evaluation = one prepared library call (outputs allocated once, pointers resolved once: what a solver loop in C
     # would do; `evaluate` spends ~6 us per call in Python, which on a busy host is the difference between a GPU-bound and a
     # host-bound 17 us evaluation -- profiles/r02_ablation.txt)
-    # Form of the evaluation.  "raw" (default where the objective has one: 2-DoF image variance on one GPU): K1 + K3 leave 32 x 6
-    # partial sums on the device and the CONSUMER folds them on the host when it reads the result (cmax_objective_raw +
-    # cmax_finalize_raw_host; here: once per run, for `loss`, as the device-result form is read once per run) -- no finishing
-    # launch.  "device": cmax_objective, loss and gradient finished on the device.  "host": cmax_objective_host, every step waits
-    # for its numbers on the host (sequential, latency-bound: what one optimiser iteration costs).
+    # Form of the evaluation.  "device" (default: the COMPLETE evaluation): cmax_objective, loss and gradient finished on the device.
+    # "raw" (2-DoF objectives on one GPU): K1 + K3 leave 32 x 6 partial sums on the device and the CONSUMER folds them on the host
+    # when it reads the result (cmax_objective_raw + cmax_finalize_raw_host; here: once per run, for `loss`) -- no finishing launch.
+    # "host": cmax_objective_host, every step waits for its numbers on the host (sequential: what one optimiser iteration costs).
     form = cfg.get("form") or args.form
     finalize = None
-    if form in ("auto", "raw") and world == 1 and handle.has_raw(desc):
+    if form == "raw" and world == 1 and handle.has_raw(desc):
         call, res, finalize = handle.prepare_raw(desc, motion_dev)
         grad, form = None, "raw"
     elif form == "host" and world == 1:
@@ -421,6 +432,12 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
                                  "kernel (instrumented passes after the timed region, same inputs; median of 5 passes)" % REPEAT)
     if keep_inputs:
         out["_inputs"] = (cfg, ev, motion)
+        if world == 1:
+            try:
+                out["launch_floor_us"] = handle.launch_floor_us()
+            except Exception as e:  # never fail the bench line over a side figure
+                out["launch_floor_us"] = None
+                out["launch_floor_error"] = f"{type(e).__name__}: {e}"[:200]
     handle.close()
     return out
 
@@ -440,10 +457,7 @@ def graph_replay_rate(cfg, ev, motion, dev, steps, windows):
         desc = E.make_descriptor(cfg["cost"], cfg["model"], sigma=cfg["sigma"])
         m = torch.from_numpy(np.asarray(motion)).to(dev).float().contiguous()
         finalize = None
-        if handle.has_raw(desc):  # the headline's own form: K1 + K3, raw sums
-            call, res, finalize = handle.prepare_raw(desc, m)
-        else:
-            call, res, grad = handle.prepare(desc, m)
+        call, res, grad = handle.prepare(desc, m)  # the headline's own form: cmax_objective
         k = steps + (steps & 1)  # even: the handle's double-buffered images end a replay where they began it
         for _ in range(50):
             call()
@@ -540,9 +554,10 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: all-reduce with torch.distributed around the phase-split calls instead of inside the library")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (1-GPU box testing with --backend gloo)")
-    ap.add_argument("--form", default="auto", choices=["auto", "raw", "device", "host"],
-                    help="how an evaluation hands over its result: auto = raw sums where the objective has that form (2-DoF image variance), "
-                         "else device; device = cmax_objective; host = cmax_objective_host (every step waits for its numbers)")
+    ap.add_argument("--form", default="device", choices=["auto", "raw", "device", "host"],
+                    help="how an evaluation hands over its result: device (default; auto is the same) = cmax_objective, loss and gradient "
+                         "finished on the device; raw = cmax_objective_raw where the objective has that form (2-DoF), the consumer folds "
+                         "the partial sums; host = cmax_objective_host (every step waits for its numbers)")
     ap.add_argument("--deterministic", action="store_true", help="cmax_set_deterministic(1): integer accumulation, bit-repeatable results (slower)")
     args = ap.parse_args()
 
@@ -580,7 +595,8 @@ def main():
         # the other configurations, fewer steps (their evaluations are 2-10x longer); same timing protocol
         # N = 1: the other single-GPU configurations, cfg5 as BASELINE states it on ONE GPU (the N = 1 point of its strong-scaling
         # curve), a working set larger than the Infinity Cache, and the headline's second rows (blur; sharp image)
-        names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_device_result", "cfg2_host_result", "cfg2_sigma1", "cfg2_structured")
+        names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_raw", "cfg2_host_result", "cfg2_sigma1", "cfg2_structured",
+                              "cfg2_theta80", "cfg3_rough", "cfg5_rough")
                   if w != args.workload]
                  if world == 1 else ["cfg5_strong"])
         for wname in names:
@@ -630,6 +646,11 @@ def main():
                          "scope": "one evaluation (SURVEY 8d: B = 24 N + 16 HW + B_model algorithmic bytes / median step time), per GPU",
                          "achieved": main_res["evaluation_GBps_per_gpu"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": main_res["evaluation_frac"],
+                         # the same evaluation in its other two forms (also.cfg2_raw / also.cfg2_host_result), when those rows ran
+                         "frac_raw_form": also.get("cfg2_raw", {}).get("evaluation_frac") if args.workload == "cfg2" else None,
+                         "frac_host_result": also.get("cfg2_host_result", {}).get("evaluation_frac") if args.workload == "cfg2" else None,
+                         # two dependent EMPTY launches with this evaluation's grids, measured in this run (cmax_debug_launch_floor)
+                         "launch_floor_us": main_res.get("launch_floor_us"),
                          "algorithmic_bytes_per_evaluation": main_res["evaluation_bytes_per_gpu"],
                          "traffic": sum(v for v in (measured_traffic(args.workload, k) for k in ("vote", "stats", "gimage", "grad", "finish")) if v) or None,
                          "traffic_source": traffic_source(args.workload),

@@ -116,6 +116,7 @@ SIGNATURES = {
     "cmax_objective_raw": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp]),
     "cmax_finalize_raw_host": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp]),
     "cmax_objective_hvp": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
+    "cmax_objective_hvp_dist": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_vote": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "cmax_set_deterministic": (c_int, [c_vp, c_int]),
@@ -134,6 +135,7 @@ SIGNATURES = {
     "cmax_read_profile": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     "cmax_copy_iwe": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "cmax_handle_info": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "cmax_debug_launch_floor": (c_int, [c_vp, c_int, c_vp]),
     "cmax_batch_info": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cmax_work_list_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cmax_sizeof_patch_objective": (c_int, []),

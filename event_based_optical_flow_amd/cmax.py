@@ -86,6 +86,8 @@ class CMaxHandle:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            if getattr(self, "_comm_init_thread", None) is not None and self._comm_init_pending():
+                return  # deliberately leaked: a timed-out cmax_comm_init still holds the native handle (comm_init)
             self._lib.cmax_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -150,6 +152,18 @@ class CMaxHandle:
         n = ctypes.c_int64()
         check(self._lib.cmax_handle_info(self._h, ctypes.byref(n), None))
         return n.value
+
+    def launch_floor_us(self, pairs: int = 200) -> float:
+        """Microseconds per pair of dependent EMPTY launches with the grids of K1 and K3 on the current batch (cmax_debug_launch_floor),
+        bracketed by events on the current stream: the floor of the headline evaluation's launch structure, measured in this run."""
+        stream = F._stream()
+        check(self._lib.cmax_debug_launch_floor(self._h, 20, stream))  # warm-up
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        check(self._lib.cmax_debug_launch_floor(self._h, int(pairs), stream))
+        t1.record()
+        t1.synchronize()
+        return t0.elapsed_time(t1) * 1e3 / pairs
 
     @property
     def workspace_bytes(self) -> int:
@@ -422,6 +436,10 @@ class CMaxHandle:
         t.start()
         t.join(timeout_s)
         if t.is_alive():
+            # The thread is still inside ncclCommInitRank and holds the raw handle: the handle must outlive it (a
+            # cmax_comm_destroy / cmax_destroy now, followed by the stuck call returning, is a use-after-free or a leaked
+            # communicator).  comm_destroy / close wait for it when it has ended by then, and otherwise leave the native handle alone.
+            self._comm_init_thread = t
             raise _lib.CmaxError(_lib.ECOMM, f"cmax_comm_init did not return within {timeout_s:.0f} s: a rank never reached ncclCommInitRank")
         if "exc" in out:
             raise out["exc"]
@@ -441,7 +459,20 @@ class CMaxHandle:
         check(self._lib.cmax_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v)))
         return n.value, r.value, v.value
 
+    def _comm_init_pending(self) -> bool:
+        """True while a timed-out cmax_comm_init is still running on this handle (see comm_init)."""
+        t = getattr(self, "_comm_init_thread", None)
+        if t is None:
+            return False
+        t.join(0.0)
+        if t.is_alive():
+            return True
+        self._comm_init_thread = None
+        return False
+
     def comm_destroy(self):
+        if self._comm_init_pending():
+            raise _lib.CmaxError(-3, "a timed-out cmax_comm_init is still running on this handle")
         check(self._lib.cmax_comm_destroy(self._h))
 
     def comm_allreduce(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:

@@ -67,6 +67,14 @@ __attribute__((visibility("hidden"))) int voxel_construct_adj_f64(const double *
 __attribute__((visibility("hidden"))) int voxel_construct_adj_tan_f64(const double *V, const double *dV, int Tn, int t0, int H, int W, int scheme,
                                                                    double *gV, double *dgV, hipStream_t s, bool det);
 __attribute__((visibility("hidden"))) bool handle_is_deterministic(cmax_handle_t h);
+// time-sliced batches (cmax_fused.hip, for the patch plan): does the handle hold a communicator; cmax_objective_dist / the product
+// with the motion gradient left as this rank's share; in-place sum over the ranks on the handle's communicator (a no-op without one)
+__attribute__((visibility("hidden"))) bool handle_has_comm(cmax_handle_t h);
+__attribute__((visibility("hidden"))) int objective_dist_local_grad(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result,
+                                                                 void *grad, hipStream_t s);
+__attribute__((visibility("hidden"))) int objective_hvp_dist_local(cmax_handle_t h, const cmax_objective_t *d, const float *motion,
+                                                                const float *tangent, void *hv, hipStream_t s);
+__attribute__((visibility("hidden"))) int handle_allreduce_sum(cmax_handle_t h, void *buf, size_t count, bool f64, hipStream_t s);
 
 // ---- wave / block reductions (64-wide) -------------------------------------------------------
 // DPP on the VALU instead of ds_bpermute shuffles (~16 cycles each on gfx950): 4 row shifts, then lane 15 of

@@ -1560,7 +1560,7 @@ k_finish_lines(const double *__restrict__ raw, int n_ref, double *__restrict__ g
         gtheta[0] = g0;
         gtheta[1] = g1;
     }
-    if (flag) {
+    if (flag) {  // (ONE wave: every lane's stores above have left it when the fence returns, so lane 63 may publish for all of them)
         __threadfence_system();
         if (lane == kWave - 1) *flag = seq;
     }
@@ -1600,6 +1600,8 @@ namespace cmax {
 #undef CMAX_THREADS
 #undef CMAX_EVENT_NS
 #undef CMAX_SLOTS
+
+__global__ void k_empty(const int4 *) {}  // cmax_debug_launch_floor
 
 // 2-DoF only: gradient = sum of the per-segment partials of every K3 launch (one workgroup).
 __global__ void __launch_bounds__(256)
@@ -2080,10 +2082,14 @@ static int pinned_reserve(T **p, int64_t *cap, int64_t count) {
     *p = nullptr;
     *cap = 0;
     const int64_t want = count + count / 2 + 64;
-    if (hipHostMalloc((void **)p, (size_t)want * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+    // coherent + mapped: kernels write results and run counters straight into these buffers and the host polls them
+    // (cmax_objective_host, the patch plan's tail) -- visibility must not hang on HIP_HOST_COHERENT; zeroed: a flag word is polled
+    // before anything ever wrote it
+    if (hipHostMalloc((void **)p, (size_t)want * sizeof(T), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         set_error("hipHostMalloc(%lld bytes) failed", (long long)(want * sizeof(T)));
         return CMAX_ENOMEM;
     }
+    std::memset((void *)*p, 0, (size_t)want * sizeof(T));
     *cap = want;
     return 0;
 }
@@ -2678,6 +2684,48 @@ static bool two_dof_lines(const cmax_handle_s *h, const cmax_objective_t *d, con
     return !h->deterministic && grad && d->model == CMAX_MODEL_2DOF && h->n > 0;
 }
 
+// C2 in row bands (cmax_comm_set_c2_bands).  WHETHER the gradient is exchanged in bands, and in which, must not depend on anything a
+// rank knows about its own slice (a rank without events, or whose work list is not group-aligned, issued ONE all-reduce
+// while its peers issued `bands` grouped ones -- different collective sequences, i.e. a hang): the bands follow from the sensor's tile
+// rows and the setting alone, every rank issues the same `bands` grouped all-reduces on its second stream, and only HOW its K3 runs
+// in front of them is local -- band by band where the work list allows it (overlap), in one launch or not at all otherwise.
+static int c2_band_count(const cmax_handle_s *h, const cmax_objective_t *d, const void *grad, cmax::Comm *c2_comm) {
+    return (c2_comm && grad && d->model == CMAX_MODEL_DENSE && h->c2_bands > 1) ? std::min(h->c2_bands, h->ntr) : 1;
+}
+static int c2_prepare_bands(cmax_handle_s *h, int bands) {
+    if (!h->comm_stream) CMAX_CHECK_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    while ((int)h->band_ev.size() < bands + 1) {
+        hipEvent_t e = nullptr;
+        CMAX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->band_ev.push_back(e);
+    }
+    return 0;
+}
+// band b's rows of both channels, all-reduced on the second stream once `s` has passed this point
+static int c2_exchange_band(cmax_handle_s *h, cmax::Comm *c2_comm, float *grad, int b, int bands, hipStream_t s) {
+    const int tr0 = (int)((int64_t)h->ntr * b / bands), tr1 = (int)((int64_t)h->ntr * (b + 1) / bands);
+    const int64_t hw = (int64_t)h->H * h->W;
+    CMAX_CHECK_HIP(hipEventRecord(h->band_ev[b], s));
+    CMAX_CHECK_HIP(hipStreamWaitEvent(h->comm_stream, h->band_ev[b], 0));
+    const int r0 = tr0 * kTile, r1 = std::min(tr1 * kTile, h->H);
+    void *bufs[2] = {grad + (int64_t)r0 * h->W, grad + hw + (int64_t)r0 * h->W};
+    const size_t counts[2] = {(size_t)(r1 - r0) * h->W, (size_t)(r1 - r0) * h->W};
+    const CommType types[2] = {kCommF32, kCommF32};
+    return comm_allreduce_group(c2_comm, bufs, counts, types, 2, kCommSum, h->comm_stream);
+}
+// the reduced gradient back to the caller's stream
+static int c2_join_bands(cmax_handle_s *h, int bands, hipStream_t s) {
+    CMAX_CHECK_HIP(hipEventRecord(h->band_ev[bands], h->comm_stream));
+    CMAX_CHECK_HIP(hipStreamWaitEvent(s, h->band_ev[bands], 0));
+    return 0;
+}
+// every band behind a gradient that is already complete on this rank
+static int c2_exchange_all_bands(cmax_handle_s *h, cmax::Comm *c2_comm, float *grad, int bands, hipStream_t s) {
+    int rc = c2_prepare_bands(h, bands);
+    for (int b = 0; b < bands && !rc; ++b) rc = c2_exchange_band(h, c2_comm, grad, b, bands, s);
+    return rc ? rc : c2_join_bands(h, bands, s);
+}
+
 static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *images, int n_images,
                             float *zero_next, double *result, void *grad, hipStream_t s, bool reuse_windows, double *raw = nullptr,
                             bool raw_is_reset = false, bool raw_only = false, cmax::Comm *c2_comm = nullptr, bool *c2_done = nullptr,
@@ -2787,8 +2835,14 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         CMAX_CHECK_LAUNCH();
     }
     if (!grad) return 0;
+    const int bands = c2_band_count(h, d, grad, c2_comm);  // the same on every rank
     if (h->n == 0) {  // this rank holds no events of the batch
         CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+        if (bands > 1) {  // ... and still takes part in every band's exchange
+            rc = c2_exchange_all_bands(h, c2_comm, (float *)grad, bands, s);
+            if (rc) return rc;
+            if (c2_done) *c2_done = true;
+        }
         return 0;
     }
 
@@ -2897,16 +2951,9 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // every gradient element of its segments' tiles, so after the launch that covers tile rows [a, b) the pixel rows [16 a, 16 b)
     // of both channels are final on this rank: they are all-reduced on the handle's second stream while the caller's stream
     // already runs the next band's K3.  One event per band hands the rows over, one event hands the reduced gradient back.
-    const int bands = (c2_comm && owned && d->model == CMAX_MODEL_DENSE && (int)h->row_seg_start.size() == h->ntr + 1)
-                          ? std::min(h->c2_bands, h->ntr) : 1;
-    if (bands > 1) {
-        if (!h->comm_stream) CMAX_CHECK_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-        while ((int)h->band_ev.size() < bands + 1) {
-            hipEvent_t e = nullptr;
-            CMAX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->band_ev.push_back(e);
-        }
-        const int64_t hw = (int64_t)h->H * h->W;
+    if (bands > 1 && owned && (int)h->row_seg_start.size() == h->ntr + 1) {  // K3 band by band, each band's rows exchanged behind it
+        rc = c2_prepare_bands(h, bands);
+        if (rc) return rc;
         for (int b = 0; b < bands; ++b) {
             const int tr0 = (int)((int64_t)h->ntr * b / bands), tr1 = (int)((int64_t)h->ntr * (b + 1) / bands);
             const int s0 = h->row_seg_start[tr0], s1 = h->row_seg_start[tr1];
@@ -2915,17 +2962,11 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             rb.shifts += (int64_t)s0 * (h->big ? 512 : 256);
             if (s1 > s0) launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, rb, d->n_ref, fold, op, nullptr, (float *)grad, b == 0 ? res : nullptr, owned, s, s0, s1 - s0);
             CMAX_CHECK_LAUNCH();
-            CMAX_CHECK_HIP(hipEventRecord(h->band_ev[b], s));
-            CMAX_CHECK_HIP(hipStreamWaitEvent(h->comm_stream, h->band_ev[b], 0));
-            const int r0 = tr0 * kTile, r1 = std::min(tr1 * kTile, h->H);
-            void *bufs[2] = {(float *)grad + (int64_t)r0 * h->W, (float *)grad + hw + (int64_t)r0 * h->W};
-            const size_t counts[2] = {(size_t)(r1 - r0) * h->W, (size_t)(r1 - r0) * h->W};
-            const CommType types[2] = {kCommF32, kCommF32};
-            rc = comm_allreduce_group(c2_comm, bufs, counts, types, 2, kCommSum, h->comm_stream);
+            rc = c2_exchange_band(h, c2_comm, (float *)grad, b, bands, s);
             if (rc) return rc;
         }
-        CMAX_CHECK_HIP(hipEventRecord(h->band_ev[bands], h->comm_stream));
-        CMAX_CHECK_HIP(hipStreamWaitEvent(s, h->band_ev[bands], 0));
+        rc = c2_join_bands(h, bands, s);
+        if (rc) return rc;
         if (c2_done) *c2_done = true;
         return 0;
     }
@@ -2942,6 +2983,14 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         else
             hipLaunchKernelGGL(k_fixed_to_grad, dim3(stream_grid(gcount, 256)), dim3(256), 0, s, h->g64, (float *)grad, gcount, h->d_det_inv_scale);
         CMAX_CHECK_LAUNCH();
+    }
+    if (bands > 1) {  // this rank's work list does not allow K3 in bands (or the mode is deterministic): the same exchanges behind one launch
+        rc = c2_exchange_all_bands(h, c2_comm, (float *)grad, bands, s);
+        if (rc) return rc;
+        if (c2_done) *c2_done = true;
+        return 0;
+    }
+    if (det) {
     } else if (deferred) {
         if (!raw_only) {
             ProfScope prof(h, kProfFinish, s);
@@ -3045,9 +3094,10 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
 // raw_out: non-null = stop at the raw sums of the deferred 2-DoF K3 (cmax_objective_raw; `grad` is then only a non-null marker)
 static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s,
                           cmax::Comm *comm, double *raw_out = nullptr, volatile unsigned long long *host_flag = nullptr,
-                          unsigned long long host_seq = 0) {
+                          unsigned long long host_seq = 0, bool skip_c2 = false) {
     const bool dist = comm != nullptr;  // also a 1-rank communicator: the same enqueue sequence, RCCL included
-    if (!raw_out && (h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
+    // (never with a host flag: the tangent-image path ends in kernels that know nothing of it -- ADVICE r3)
+    if (!raw_out && !host_flag && !skip_c2 && (h->n > 0 || dist) && tan2_applicable(h, d, grad, dist)) return objective_eval_tan2(h, d, motion, result, grad, s, comm);
     if (raw_out && !two_dof_lines(h, d, grad)) {
         set_error("objective_raw: this objective has no raw form (2-DoF, a non-empty batch, not deterministic)");
         return CMAX_EINVAL;
@@ -3090,7 +3140,7 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     }
     bool c2_done = false;  // the gradient was all-reduced in row bands behind K3 already
     rc = objective_finish(h, d, motion, cur, n_images, nxt, result, grad, s, true, raw, raw != nullptr, raw_out != nullptr,
-                          dist && grad && !raw_out ? comm : nullptr, &c2_done, host_flag, host_seq);
+                          dist && grad && !raw_out && !skip_c2 ? comm : nullptr, &c2_done, host_flag, host_seq);
     if (h->mu_valid) {  // K1 summed its votes and nothing consumed (and cleared) them -- an error on the way, or a path that does
         // not use them after all: the next evaluation must find clean accumulators
         (void)hipMemsetAsync(h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride, 0, (size_t)4 * kMuStride * sizeof(double), s);
@@ -3099,7 +3149,7 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     if (rc) return rc;
     h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
     h->cur_buf ^= 1;
-    if (dist && grad && !raw_out && !c2_done) {  // C2
+    if (dist && grad && !raw_out && !c2_done && !skip_c2) {  // C2
         ProfScope prof(h, kProfComm, s);
         rc = comm_allreduce(comm, grad, (size_t)gcount, d->model == CMAX_MODEL_2DOF ? kCommF64 : kCommF32, kCommSum, s);
         if (rc) return rc;
@@ -3186,6 +3236,16 @@ static int spin_until_done(hipStream_t s) {
     return 0;
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
+
 int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, double *result_host, void *grad_host,
                         cmax_stream_t stream) {
     const float *motion = static_cast<const float *>(motion_v);
@@ -3211,7 +3271,7 @@ int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *d, const void *
                 seen = true;
                 break;
             }
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         if (!seen) {
             rc = spin_until_done(s);
@@ -3369,20 +3429,20 @@ static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams
 
 extern "C" {
 
-int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, const float *tangent, void *hv,
-                       cmax_stream_t stream) {
-    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
-    int rc = check_objective_args(h, d, motion);
-    if (rc) return rc;
-    CMAX_REQUIRE(tangent && hv, "objective_hvp: tangent / hv");
-    hipStream_t s = (hipStream_t)stream;
+// comm: the handle holds a time slice of the batch -- the images and the tangent images are all-reduced (ONE grouped call: both are
+// sums over events), everything in image space runs redundantly on every rank, the second-order gather covers this rank's events;
+// reduce_hv: ... and the product is all-reduced too (cmax_objective_hvp_dist); the patch plan reduces its 2 n_patch numbers instead
+static int objective_hvp_impl(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *tangent, void *hv, hipStream_t s,
+                              cmax::Comm *comm, bool reduce_hv) {
+    int rc = 0;
+    const bool dist = comm != nullptr;
     const int Hp = h->Hp, Wp = h->Wp;
     const int64_t npix = (int64_t)Hp * Wp;
     const bool two_dof = d->model == CMAX_MODEL_2DOF;
     const int64_t gcount = two_dof ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
     const size_t gbytes = two_dof ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
     CMAX_CHECK_HIP(hipMemsetAsync(hv, 0, gbytes, s));
-    if (h->n == 0) return 0;
+    if (h->n == 0 && !dist) return 0;
     if (!h->hvp_img) {
         rc = dev_alloc(h, &h->hvp_img, 6 * 4 * npix);
         if (!rc) rc = dev_alloc(h, &h->d_stat_tan, 4 * kStatStride);
@@ -3405,6 +3465,11 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
     if (d->normalized && !orig_cache_hit(h, d)) {
         rc = vote_image(h, -1, nullptr, 0, CMAX_REF_FIRST, 0.0, 1, I, false, 4, s);
         if (rc) return rc;
+        if (dist) {
+            ProfScope prof(h, kProfComm, s);
+            rc = comm_allreduce(comm, I, (size_t)npix, kCommF32, kCommSum, s);
+            if (rc) return rc;
+        }
         const float *img = nullptr;
         rc = blur_image(h, d->sigma, I, Ib, &img, s);
         if (rc) return rc;
@@ -3445,6 +3510,46 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
         rc = vote_images(h, d->model, motion, d->T, nr, d->ref_mode, d->ref_frac, d->normalize_t, imgs, 0xFu, 0, s);
         if (rc) return rc;
     }
+    // T1: tangent images (their blur follows below)
+    CMAX_CHECK_HIP(hipMemsetAsync(dI, 0, (size_t)nr * npix * sizeof(float), s));
+    // deterministic mode (round 3): the tangent votes go to the integer images (all zero between uses) and are rounded to fp32
+    // once; the second-order gather below accumulates integers -- the product is then bit-identical from run to run like the
+    // loss and the gradient
+    const bool det = h->deterministic;
+    long long *dI64 = det ? h->img64 : nullptr;
+    if (h->n > 0) {
+        switch (d->model) {
+            case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, dI, s, dI64); break;
+            case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, dI, s, dI64); break;
+            default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, dI, s, dI64); break;
+        }
+    }
+    CMAX_CHECK_LAUNCH();
+    if (det && h->n > 0) {
+        FixedArgs fa = {};
+        for (int k = 0; k < nr; ++k) {
+            fa.src[k] = h->img64 + (int64_t)k * npix;
+            fa.dst[k] = dI + k * npix;
+            fa.inv_fixk[k] = 1.0 / (double)tp.fixk[k];
+        }
+        hipLaunchKernelGGL(k_fixed_to_image, dim3(stream_grid(npix, 256), nr), dim3(256), 0, s, fa, npix);
+        CMAX_CHECK_LAUNCH();
+    }
+    if (dist) {  // C1 of the product: images and tangent images of all reference times, one grouped call
+        ProfScope prof(h, kProfComm, s);
+        void *bufs[2] = {I, dI};
+        const size_t counts[2] = {(size_t)nr * npix, (size_t)nr * npix};
+        const CommType types[2] = {kCommF32, kCommF32};
+        rc = comm_allreduce_group(comm, bufs, counts, types, 2, kCommSum, s);
+        if (rc) return rc;
+    }
+    if (h->n == 0) {  // this rank holds no events of the batch: nothing to gather, but it takes part in every exchange
+        if (dist && reduce_hv) {
+            ProfScope prof(h, kProfComm, s);
+            rc = comm_allreduce(comm, hv, (size_t)gcount, two_dof ? kCommF64 : kCommF32, kCommSum, s);
+        }
+        return rc;
+    }
     const float *img = I, *dimg = dI;
     if (d->sigma > 0) {
         hipLaunchKernelGGL(k_blur3<float>, igrid, dim3(256), 0, s, I, Hp, Wp, (float)k0, (float)k1, Ib, bs);
@@ -3455,29 +3560,7 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
     else
         hipLaunchKernelGGL(k_stats<CMAX_COST_GRADMAG>, sgrid, dim3(256), 0, s, img, Hp, Wp, d->omit_boundary, nsub, h->d_stat, (float *)nullptr, (float4 *)nullptr, (int64_t)0, bs);
     CMAX_CHECK_LAUNCH();
-    // T1: tangent images and their blur
-    CMAX_CHECK_HIP(hipMemsetAsync(dI, 0, (size_t)nr * npix * sizeof(float), s));
-    // deterministic mode (round 3): the tangent votes go to the integer images (all zero between uses) and are rounded to fp32
-    // once; the second-order gather below accumulates integers -- the product is then bit-identical from run to run like the
-    // loss and the gradient
-    const bool det = h->deterministic;
-    long long *dI64 = det ? h->img64 : nullptr;
-    switch (d->model) {
-        case CMAX_MODEL_2DOF: launch_vote_tan<CMAX_MODEL_2DOF>(h, ev, wp, tp, nr, dI, s, dI64); break;
-        case CMAX_MODEL_DENSE: launch_vote_tan<CMAX_MODEL_DENSE>(h, ev, wp, tp, nr, dI, s, dI64); break;
-        default: launch_vote_tan<CMAX_MODEL_VOXEL>(h, ev, wp, tp, nr, dI, s, dI64); break;
-    }
-    CMAX_CHECK_LAUNCH();
-    if (det) {
-        FixedArgs fa = {};
-        for (int k = 0; k < nr; ++k) {
-            fa.src[k] = h->img64 + (int64_t)k * npix;
-            fa.dst[k] = dI + k * npix;
-            fa.inv_fixk[k] = 1.0 / (double)tp.fixk[k];
-        }
-        hipLaunchKernelGGL(k_fixed_to_image, dim3(stream_grid(npix, 256), nr), dim3(256), 0, s, fa, npix);
-        CMAX_CHECK_LAUNCH();
-    }
+    // (the tangent images were voted above, next to the images)
     if (d->sigma > 0) {
         hipLaunchKernelGGL(k_blur3<float>, igrid, dim3(256), 0, s, dI, Hp, Wp, (float)k0, (float)k1, dIb, bs);
         dimg = dIb;
@@ -3543,8 +3626,58 @@ int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *m
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, h->d_gpart, d->n_ref * h->nseg, (double *)hv);
         CMAX_CHECK_LAUNCH();
     }
+    if (dist && reduce_hv) {
+        ProfScope prof(h, kProfComm, s);
+        rc = comm_allreduce(comm, hv, (size_t)gcount, two_dof ? kCommF64 : kCommF32, kCommSum, s);
+        if (rc) return rc;
+    }
     return 0;
 }
+
+int cmax_objective_hvp(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, const float *tangent, void *hv,
+                       cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);  // double theta[2] when d->motion_dtype == CMAX_F64
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(tangent && hv, "objective_hvp: tangent / hv");
+    return objective_hvp_impl(h, d, motion, tangent, hv, (hipStream_t)stream, nullptr, false);
+}
+
+int cmax_objective_hvp_dist(cmax_handle_t h, const cmax_objective_t *d, const void *motion_v, const float *tangent, void *hv,
+                            cmax_stream_t stream) {
+    const float *motion = static_cast<const float *>(motion_v);
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    CMAX_REQUIRE(tangent && hv, "objective_hvp_dist: tangent / hv");
+    return objective_hvp_impl(h, d, motion, tangent, hv, (hipStream_t)stream, h->comm, true);
+}
+
+}  // extern "C"
+
+// library-internal (cmax_solver.hip): the evaluation / the product of a time-sliced batch with the motion gradient LEFT AS THIS
+// RANK'S SHARE -- the patch plan carries it through the (linear) adjoints of the voxel chain and of the patch interpolation and
+// all-reduces 2 n_patch numbers instead of 2 H W [T]
+namespace cmax {
+bool handle_has_comm(cmax_handle_t h) { return h && h->comm != nullptr; }
+int objective_dist_local_grad(cmax_handle_t h, const cmax_objective_t *d, const float *motion, double *result, void *grad, hipStream_t s) {
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    return objective_eval(h, d, motion, result, grad, s, h->comm, nullptr, nullptr, 0, true);
+}
+int objective_hvp_dist_local(cmax_handle_t h, const cmax_objective_t *d, const float *motion, const float *tangent, void *hv, hipStream_t s) {
+    int rc = check_objective_args(h, d, motion);
+    if (rc) return rc;
+    return objective_hvp_impl(h, d, motion, tangent, hv, s, h->comm, false);
+}
+int handle_allreduce_sum(cmax_handle_t h, void *buf, size_t count, bool f64, hipStream_t s) {
+    if (!h || !h->comm) return 0;
+    ProfScope prof(h, kProfComm, s);
+    return comm_allreduce(h->comm, buf, count, f64 ? kCommF64 : kCommF32, kCommSum, s);
+}
+}  // namespace cmax
+
+extern "C" {
+
 
 int cmax_sizeof_objective(void) { return (int)sizeof(cmax_objective_t); }
 
@@ -3671,6 +3804,22 @@ int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_byte
     CMAX_REQUIRE(h != nullptr, "handle_info");
     if (n_events) *n_events = h->n;
     if (workspace_bytes) *workspace_bytes = h->bytes;
+    return 0;
+}
+
+// Launch floor of the current work list: `pairs` times two dependent EMPTY launches with the grids of K1 and K3 of a single-reference
+// objective on this batch (the launch structure of the headline evaluation).  bench.py brackets it with events: what the evaluation
+// would cost if its kernels did nothing (profiles/r03_launch_floor.txt measured the same with tools/microbench_launch.hip).
+int cmax_debug_launch_floor(cmax_handle_t h, int pairs, cmax_stream_t stream) {
+    CMAX_REQUIRE(h != nullptr && pairs > 0, "debug_launch_floor");
+    CMAX_REQUIRE(h->n > 0 && h->nseg > 0, "debug_launch_floor: no events set");
+    const dim3 grid(8 * ((h->nseg + 7) / 8));
+    const int k1 = h->big ? 512 : (h->nseg > 512 ? 512 : 256), k3 = grad_threads(h, CMAX_MODEL_2DOF);
+    for (int i = 0; i < pairs; ++i) {
+        hipLaunchKernelGGL(k_empty, grid, dim3(k1), 0, (hipStream_t)stream, h->d_segs);
+        hipLaunchKernelGGL(k_empty, grid, dim3(k3), 0, (hipStream_t)stream, h->d_segs);
+    }
+    CMAX_CHECK_LAUNCH();
     return 0;
 }
 

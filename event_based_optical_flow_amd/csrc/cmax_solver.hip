@@ -215,6 +215,27 @@ int plan_alloc(T **p, int64_t count) {
     return 0;
 }
 
+// Time-sliced batches (the handle holds a communicator, cmax_comm_init): the solver's objective is evaluated the way
+// cmax_objective_dist evaluates a fused term -- K1 -> all-reduce(images) -> image kernels -> K3 on this rank's events -- but the
+// flow gradient is NOT exchanged (2 H W [T] floats: 7.4 MB at 720p).  Every step from there to the optimiser's gradient is linear
+// (weighted sum over the terms, adjoint sweep of the voxel chain, adjoint of the patch interpolation), so each rank carries its
+// share through them and the ranks all-reduce 2 n_patch numbers (4 KB for a 16 x 16 grid) in front of the tail kernel.  Loss,
+// total variation and everything derived from x are computed redundantly and identically on every rank.
+int plan_objective(cmax_patch_plan_s *p, const cmax_objective_t *term, double *result, void *grad, hipStream_t s) {
+    if (handle_has_comm(p->handle)) return objective_dist_local_grad(p->handle, term, p->motion32, result, grad, s);
+    return cmax_objective(p->handle, term, p->motion32, result, grad, s);
+}
+int plan_objective_hvp(cmax_patch_plan_s *p, const cmax_objective_t *term, void *hv, hipStream_t s) {
+    if (handle_has_comm(p->handle)) return objective_hvp_dist_local(p->handle, term, p->motion32, p->tan32, hv, s);
+    return cmax_objective_hvp(p->handle, term, p->motion32, p->tan32, hv, s);
+}
+// C2 of the plan: the gradient (or product) w.r.t. the patch motion, summed over the ranks (a no-op without a communicator)
+int plan_reduce_gx(cmax_patch_plan_s *p, const double *gx64, const float *gx32, hipStream_t s) {
+    if (!handle_has_comm(p->handle)) return 0;
+    if (gx64) return handle_allreduce_sum(p->handle, const_cast<double *>(gx64), (size_t)p->nx, true, s);
+    return handle_allreduce_sum(p->handle, const_cast<float *>(gx32), (size_t)p->nx, false, s);
+}
+
 // x (host) -> fp32 motion of the fused objective: flow [2,H,W] or voxel [T,2,H,W] in pixel per normalised time.
 // Leaves the fp64 flow (scaled) in flow64 and, when time-aware, the fp64 voxel in vox64.
 int forward_motion(cmax_patch_plan_s *p, const double *src64, double scale, const double *scale_dev, float *dst32, hipStream_t s) {
@@ -292,7 +313,7 @@ int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t 
     if (rc) return rc;
     const bool accumulate = want_grad && !(d.n_terms == 1 && !d.time_aware);
     for (int i = 0; i < d.n_terms; ++i) {
-        rc = cmax_objective(p->handle, &d.term[i], p->motion32, p->results + 8 * i, want_grad ? p->grad32 : nullptr, s);
+        rc = plan_objective(p, &d.term[i], p->results + 8 * i, want_grad ? p->grad32 : nullptr, s);
         if (rc) return rc;
         if (accumulate) {
             hipLaunchKernelGGL(k_accumulate, dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64);
@@ -304,6 +325,7 @@ int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t 
     double wscale = 1.0;
     if (want_grad) {
         rc = backward_motion(p, &gx64, &gx32, &wscale, s);
+        if (!rc) rc = plan_reduce_gx(p, gx64, gx32, s);
         if (rc) return rc;
     }
     FinalParams fp;
@@ -353,11 +375,11 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
     hipLaunchKernelGGL((k_convert_scale<float, double>), dim3(mgrid), dim3(256), 0, s, p->dvox64, p->nmotion, 1.0, p->scal + 1, p->tan32);
     CMAX_CHECK_LAUNCH();
     for (int i = 0; i < d.n_terms; ++i) {
-        rc = cmax_objective(p->handle, &d.term[i], p->motion32, p->results + 8 * i, p->grad32, s);  // g_V
+        rc = plan_objective(p, &d.term[i], p->results + 8 * i, p->grad32, s);  // g_V (time-sliced batch: this rank's share, like everything below)
         if (rc) return rc;
         hipLaunchKernelGGL(k_accumulate, dim3(mgrid), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64, (const double *)nullptr);
         CMAX_CHECK_LAUNCH();
-        rc = cmax_objective_hvp(p->handle, &d.term[i], p->motion32, p->tan32, p->grad32, s);  // H_VV dV / max|dV|
+        rc = plan_objective_hvp(p, &d.term[i], p->grad32, s);  // H_VV dV / max|dV|
         if (rc) return rc;
         hipLaunchKernelGGL(k_accumulate, dim3(mgrid), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->dgacc64, (const double *)p->scal);
         CMAX_CHECK_LAUNCH();
@@ -366,6 +388,7 @@ int enqueue_hvp_time_aware(cmax_patch_plan_s *p, hipStream_t s) {
     rc = voxel_construct_adj_tan_f64(p->vox64, p->dvox64, d.T, d.t0, d.H, d.W, d.scheme, p->gacc64, p->dgacc64, s, handle_is_deterministic(p->handle));
     if (rc) return rc;
     rc = cmax_patch_to_dense(p->dgacc64 + (int64_t)d.t0 * p->nflow, CMAX_F64, d.ph, d.pw, d.pad_h, d.pad_w, d.sw_h, d.sw_w, d.H, d.W, 1, p->gx64, s);
+    if (!rc) rc = plan_reduce_gx(p, p->gx64, nullptr, s);
     if (rc) return rc;
     FinalParams fp;
     fp.n_terms = 0;
@@ -397,7 +420,7 @@ int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
     if (rc) return rc;
     const bool accumulate = !(d.n_terms == 1 && !d.time_aware);
     for (int i = 0; i < d.n_terms; ++i) {
-        rc = cmax_objective_hvp(p->handle, &d.term[i], p->motion32, p->tan32, p->grad32, s);
+        rc = plan_objective_hvp(p, &d.term[i], p->grad32, s);
         if (rc) return rc;
         if (accumulate) {
             hipLaunchKernelGGL(k_accumulate, dim3(div_up(p->nmotion, 256)), dim3(256), 0, s, p->grad32, p->nmotion, d.weight[i], i == 0 ? 1 : 0, p->gacc64);
@@ -408,6 +431,7 @@ int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
     const float *gx32 = nullptr;
     double wscale = 1.0;
     rc = backward_motion(p, &gx64, &gx32, &wscale, s);
+    if (!rc) rc = plan_reduce_gx(p, gx64, gx32, s);
     if (rc) return rc;
     FinalParams fp;
     fp.n_terms = 0;
@@ -461,7 +485,11 @@ static int wait_for_tail(cmax_patch_plan_s *p, hipStream_t s, bool poll) {
                 p->seq_seen = expected;
                 return 0;
             }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#elif defined(__aarch64__)
+            asm volatile("yield" ::: "memory");
+#endif
         }
     }
     CMAX_CHECK_HIP(hipStreamSynchronize(s));
@@ -483,7 +511,7 @@ int run_sequence(cmax_patch_plan_s *p, int kind, hipStream_t caller, F enqueue) 
         drop_graphs(p);  // new events behind the handle: other device pointers, another work list
         p->eager_calls = 0;
     }
-    const bool eager = !p->graphs_ok || pre.profiling || p->eager_calls < 3;
+    const bool eager = !p->graphs_ok || pre.profiling || p->eager_calls < 3 || handle_has_comm(p->handle);  // (collectives are never captured)
     if (eager) {
         ++p->eager_calls;
         int rc = enqueue(caller);
@@ -574,7 +602,7 @@ int cmax_patch_plan_create(cmax_handle_t h, const cmax_patch_objective_t *desc, 
     if (!rc && hipHostMalloc((void **)&p->h_in, (2 * (size_t)p->nx + 2) * sizeof(double)) != hipSuccess) rc = CMAX_ENOMEM;
     if (!rc && hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) rc = CMAX_ENOMEM;
     if (!rc && hipEventCreateWithFlags(&p->ev_caller, hipEventDisableTiming) != hipSuccess) rc = CMAX_ENOMEM;
-    if (!rc && hipHostMalloc((void **)&p->h_out, (2 + (size_t)p->nx) * sizeof(double), hipHostMallocMapped) != hipSuccess) rc = CMAX_ENOMEM;
+    if (!rc && hipHostMalloc((void **)&p->h_out, (2 + (size_t)p->nx) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) rc = CMAX_ENOMEM;
     if (!rc && hipHostGetDevicePointer((void **)&p->h_out_dev, p->h_out, 0) != hipSuccess) {
         (void)hipGetLastError();
         p->h_out_dev = p->h_out;  // unified addressing: pinned host memory is addressable from the device as it is

@@ -332,17 +332,24 @@ int cmax_comm_info(cmax_handle_t h, int *nranks, int *rank, int *rccl_version);
 /* In-place all-reduce of a device buffer on the handle's communicator (dtype CMAX_F32 / CMAX_F64;
  * op 0 sum, 1 min, 2 max) -- e.g. (t_min, -t_max) with op min to agree on the batch extremes.   */
 int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, int op, cmax_stream_t stream);
-/* Overlap of the gradient exchange with the gather (dense objectives on a group-aligned work list, cmax_batch_info's
- * owned_groups): with bands > 1 cmax_objective_dist launches its gathering kernel in `bands` bands of source-tile rows and
- * all-reduces every band's rows of the gradient on a second stream of the handle while the next band is gathered (events
- * order the two streams; the caller's stream continues after the last band is reduced).  bands = 1 (default): one launch,
- * one all-reduce behind it.  Results are the same.                                                */
+/* Overlap of the gradient exchange with the gather (dense objectives).  With bands > 1 cmax_objective_dist exchanges the gradient
+ * as `bands` grouped all-reduces of source-tile-row bands on a second stream of the handle (events order the two streams; the
+ * caller's stream continues after the last band is reduced).  EVERY RANK MUST SET THE SAME VALUE: the bands follow from the
+ * sensor's tile rows and this setting alone, so all ranks issue the same collectives whatever their own slice looks like; a
+ * rank whose work list is group-aligned (cmax_batch_info's owned_groups) launches its gathering kernel band by band, so that a
+ * band's rows are exchanged while the next band is gathered -- the others (no owned groups, deterministic mode, no events)
+ * finish their gradient first and issue the same exchanges behind it.  bands = 1 (default): one all-reduce.  Same results. */
 int cmax_comm_set_c2_bands(cmax_handle_t h, int bands);
 /* One evaluation of the whole (time-sliced) batch: same arguments and results as cmax_objective,
  * the same on every rank (the gradient bit for bit; the loss up to fp64 summation order when a rank
  * holds no events).  A rank may hold zero events.  Without a communicator: == cmax_objective.   */
 int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                         double *result, void *grad, cmax_stream_t stream);
+
+/* The exact Hessian-vector product of the whole (time-sliced) batch: cmax_objective_hvp with one grouped all-reduce of the images
+ * and the tangent images (both are sums over events) and one of the product.  Without a communicator: == cmax_objective_hvp.   */
+int cmax_objective_hvp_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
+                            const float *tangent, void *hv, cmax_stream_t stream);
 
 /* Deterministic mode ("race detection"): bit-identical IWE, loss and gradient from run
  * to run for cmax_iwe / cmax_objective / cmax_objective_vote + _finish / cmax_objective_hvp.  By default the vote flush, the flow
@@ -399,6 +406,10 @@ int cmax_work_list_info(cmax_handle_t h, int *n_segments, int *segment_events, i
 
 /* Introspection for tests / bench: number of packed events, HBM bytes held by the handle.     */
 int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_bytes);
+/* Measurement aid (bench.py's roofline.launch_floor_us): enqueues `pairs` times two dependent EMPTY kernels with the grids of
+ * the warp + vote kernel and of the gather kernel of a single-reference objective on the current batch -- what the headline
+ * evaluation's launch structure costs when its kernels do nothing.  The caller brackets the call with events on `stream`.   */
+int cmax_debug_launch_floor(cmax_handle_t h, int pairs, cmax_stream_t stream);
 
 /* =============================================================================================
  * The optimiser's objective for patch-based flow in one call: what
@@ -437,7 +448,12 @@ int cmax_patch_plan_set_t_scale(cmax_patch_plan_t plan, double t_scale);
  * CMAX_PLAN_GRAPHS=1 in the environment at plan creation, evaluations after the first few are replayed from
  * captured hipGraphs (one per distinct launch sequence; 0 again if a capture failed).                        */
 int cmax_patch_plan_info(cmax_patch_plan_t plan, int *n_graphs, int *graph_replay_enabled);
-/* x_host [2*ph*pw] -> *loss_host, grad_host [2*ph*pw] (NULL: value only).  with_tv = 0 leaves the
+/* On a handle that holds a communicator (cmax_comm_init: a time slice of the batch per rank) both calls below evaluate the WHOLE
+ * batch, the same numbers on every rank: the fused terms exchange their images like cmax_objective_dist (and the product its
+ * tangent images), but the flow gradient is not exchanged -- each rank carries its share through the (linear) adjoints of the voxel
+ * chain and of the patch interpolation, and the ranks all-reduce 2 ph pw numbers (4 KB for a 16 x 16 grid instead of 7.4 MB of flow
+ * gradient at 720p).  Every rank must make the same calls in the same order.
+ * x_host [2*ph*pw] -> *loss_host, grad_host [2*ph*pw] (NULL: value only).  with_tv = 0 leaves the
  * total_variation term out (the smooth part, differenced for time-aware Hessian-vector products).
  * Blocks until the result is on the host.                                                      */
 int cmax_patch_plan_evaluate(cmax_patch_plan_t plan, const double *x_host, int with_tv, double *loss_host,
