@@ -19,8 +19,10 @@ HEADERS = ["cmax_common.h", "cmax_image_kernels.h", "cmax_patch_kernels.h", "cma
            "cmax_sort_kernels.h", "cmax_event_kernels.inc", "cmax_comm.h", os.path.join("..", "..", "include", "cmax_hip.h")]
 # -munsafe-fp-atomics: fp32/fp64 atomicAdd lower to global_atomic_add_f32/_f64 and ds_add_f32
 # (hardware atomics) instead of compare-and-swap loops.
+# -amdgpu-kernarg-preload-count=16: the first 16 dwords of a kernel's arguments arrive in SGPRs at wave launch (gfx940+) instead
+# of through a scalar load from the argument block -- the event kernels put their work list first (cmax_event_kernels.inc).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
 LINK_LIBS = ["-ldl"]  # cmax_comm.hip binds RCCL with dlopen (no link-time dependency on librccl)
 

@@ -130,6 +130,28 @@ struct ImgArgs {
 
 }  // namespace cmax
 
+// Phase timeline of the event kernels (builds with -DCMAX_TIMELINE only, tools/timeline.py): thread 0 of the first 4096 workgroups of
+// reference time 0 stamps the 100 MHz wall clock at the phase boundaries of K1 (kernel 0) and K3 (kernel 1) into
+// g_timeline[kernel][workgroup][8]; a stamp that is to follow the arrival of loaded data is handed a value computed from it.
+#ifdef CMAX_TIMELINE
+namespace cmax {
+__device__ unsigned long long *g_timeline = nullptr;
+__device__ __forceinline__ void timeline_stamp(int kernel, int idx) {
+    if (g_timeline && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096u) g_timeline[((size_t)kernel * 4096 + blockIdx.x) * 8 + idx] = wall_clock64();
+}
+template <typename T>
+__device__ __forceinline__ void timeline_stamp_after(int kernel, int idx, T dep) {
+    asm volatile("" ::"v"(dep));
+    timeline_stamp(kernel, idx);
+}
+}  // namespace cmax
+#define CMAX_STAMP(K, I) cmax::timeline_stamp(K, I)
+#define CMAX_STAMP_AFTER(K, I, DEP) cmax::timeline_stamp_after(K, I, DEP)
+#else
+#define CMAX_STAMP(K, I) do { } while (0)
+#define CMAX_STAMP_AFTER(K, I, DEP) do { } while (0)
+#endif
+
 struct cmax_handle_s {
     int H = 0, W = 0, ph = 0, pw = 0, Hp = 0, Wp = 0;
     int device = 0;
@@ -1761,8 +1783,8 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     ProfScope prof(h, kProfVote, s);
 #define CMAX_LAUNCH_VOTE(NS, FRAC)                                                                                           \
     do {                                                                                                                    \
-        if (ra.musum[0]) hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC, true>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra); \
-        else hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);     \
+        if (ra.musum[0]) hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC, true>), grid, dim3(NS::kThr), 0, s, h->d_segs, h->nseg, ev.ev, ev, wp, ra); \
+        else hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, h->d_segs, h->nseg, ev.ev, ev, wp, ra);     \
     } while (0)
     static const int force = forced_ns("CMAX_VOTE_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
@@ -1802,8 +1824,8 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
 #define CMAX_LAUNCH_DET(FRAC, FOLD)                                                                                                         \
     do {                                                                                                                                    \
-        if (h->big) hipLaunchKernelGGL((b512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(b512::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result); \
-        else hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result); \
+        if (h->big) hipLaunchKernelGGL((b512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(b512::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
+        else hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
     } while (0)
         if (h->has_frac) {
             if (fold == kFoldStats) CMAX_LAUNCH_DET(true, kFoldStats);
@@ -1820,7 +1842,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     // owned groups (dense / voxel, one reference time, group-aligned work list): LDS accumulators + plain stores
     const bool strided = MODEL == CMAX_MODEL_DENSE && !(h->long_runs && h->n_time_bin == 0);
 #define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, VARIANT) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, ev, wp, segs, nseg, ra, op, h->d_stat, gpart, gflow, result)
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result)
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
     do {                                                                      \
         if constexpr (MODEL == CMAX_MODEL_DENSE) {                            \
@@ -3059,10 +3081,10 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
         ProfScope prof(h, kProfVote, s);
         for (int rep = 0; rep < h->prof_repeat; ++rep) {
             if (h->big) {
-                if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan2<true>), grid, dim3(b512::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
-                else hipLaunchKernelGGL((b512::k_vote_tan2<false>), grid, dim3(b512::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
-            } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan2<true>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
-            else hipLaunchKernelGGL((t256::k_vote_tan2<false>), grid, dim3(t256::kThr), 0, s, ev, wp, h->d_segs, h->nseg, ra);
+                if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan2<true>), grid, dim3(b512::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
+                else hipLaunchKernelGGL((b512::k_vote_tan2<false>), grid, dim3(b512::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
+            } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan2<true>), grid, dim3(t256::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
+            else hipLaunchKernelGGL((t256::k_vote_tan2<false>), grid, dim3(t256::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
         }
         CMAX_CHECK_LAUNCH();
     }
@@ -3805,6 +3827,20 @@ int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_byte
     if (n_events) *n_events = h->n;
     if (workspace_bytes) *workspace_bytes = h->bytes;
     return 0;
+}
+
+// tools/timeline.py: where the event kernels record their phase stamps (device buffer of 2 x 4096 x 8 u64; NULL: off).  Only
+// libraries built with -DCMAX_TIMELINE record anything; the others return CMAX_ESTATE.
+int cmax_debug_timeline(void *device_buffer) {
+#ifdef CMAX_TIMELINE
+    unsigned long long *p = static_cast<unsigned long long *>(device_buffer);
+    CMAX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cmax::g_timeline), &p, sizeof(p)));
+    return 0;
+#else
+    (void)device_buffer;
+    set_error("debug_timeline: this library was built without -DCMAX_TIMELINE");
+    return CMAX_ESTATE;
+#endif
 }
 
 // Launch floor of the current work list: `pairs` times two dependent EMPTY launches with the grids of K1 and K3 of a single-reference

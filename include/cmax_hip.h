@@ -410,6 +410,9 @@ int cmax_handle_info(cmax_handle_t h, int64_t *n_events, int64_t *workspace_byte
  * the warp + vote kernel and of the gather kernel of a single-reference objective on the current batch -- what the headline
  * evaluation's launch structure costs when its kernels do nothing.  The caller brackets the call with events on `stream`.   */
 int cmax_debug_launch_floor(cmax_handle_t h, int pairs, cmax_stream_t stream);
+/* Tuning aid (tools/timeline.py; libraries built with -DCMAX_TIMELINE only, CMAX_ESTATE otherwise): device buffer of 2 x 4096 x 8
+ * uint64 into which thread 0 of the event kernels' workgroups stamps the wall clock at its phase boundaries (NULL: off).       */
+int cmax_debug_timeline(void *device_buffer);
 
 /* =============================================================================================
  * The optimiser's objective for patch-based flow in one call: what
