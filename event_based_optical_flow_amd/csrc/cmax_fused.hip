@@ -175,6 +175,8 @@ struct cmax_handle_s {
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] source pixels with >= 1 event
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
+    bool mid = false;        // MID segments: up to 3064 events, four source tiles (five (tile, bin) groups) wide, event kernels of the m512 namespace -- when the
+                             // standard cut would need more workgroups than the chip holds at once and this one does not (build_segments)
     bool big = false;        // BIG segments: up to 4088 events each, event kernels of the b512 / b1024 namespaces (batches of >= 8M events)
     int seg_max = 2040;      // events per segment of the current work list (kSegMax, or 4088 for big segments)
     bool small_acc = false;  // binned handle, owned groups of <= 3 groups per segment: the voxel K3 with kAccCellsDense accumulator cells (kGradOwnedSmall)
@@ -929,10 +931,10 @@ k_stats(const float *__restrict__ img, int H, int W, int omit, int nsub, double 
 //   k_blur_stats_var      Ib = blur3(I) (written: K3 / cmax_copy_iwe read it), sum Ib, sum Ib^2 over Omega, zeroing
 //   k_gimage_blur_adj_var G = blur3^T [ c (Ib - mu) 1_Omega ]  with c, mu from the finished statistics
 __global__ void __launch_bounds__(256)
-k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
+k_blur_stats_var(const float *__restrict__ in0, int64_t in_stride, int H, int W, ImgArgs ia, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
                  float4 *__restrict__ zero_extra, int64_t n_extra4) {
     __shared__ double smem[2 * 4];
-    const float *__restrict__ img = ia.in[blockIdx.y];
+    const float *__restrict__ img = in0 + blockIdx.y * in_stride;  // (leading, preloaded arguments: the tile loads leave without waiting for the argument block)
     float *__restrict__ blurred = ia.blurred[blockIdx.y];
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
@@ -963,11 +965,11 @@ k_blur_stats_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsu
 
 constexpr int kGmTileH = 8, kGmTileW = 32;  // pixels per workgroup of k_stats_gimage_gm (256 threads, one pixel each)
 __global__ void __launch_bounds__(256)
-k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restrict__ stat_base, float4 *__restrict__ zero_extra,
+k_stats_gimage_gm(const float *__restrict__ in0, int64_t in_stride, int H, int W, ImgArgs ia, int omit, int nsub, double *__restrict__ stat_base, float4 *__restrict__ zero_extra,
                   int64_t n_extra4) {
     __shared__ double smem[2 * 4];
     __shared__ float tile[kGmTileH + 4][kGmTileW + 4 + 1];  // image tile with a halo of 2 (zero outside the image)
-    const float *__restrict__ img = ia.in[blockIdx.y];
+    const float *__restrict__ img = in0 + blockIdx.y * in_stride;  // (leading, preloaded arguments: the tile loads leave without waiting for the argument block)
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     float *__restrict__ G = ia.G[blockIdx.y];
     double *__restrict__ stat_slot = stat_base + blockIdx.y * kStatStride;
@@ -1042,10 +1044,10 @@ k_stats_gimage_gm(ImgArgs ia, int H, int W, int omit, int nsub, double *__restri
 // One 8 x 32 output tile per workgroup; the stages shrink a halo of 4 -> 3 -> 2 -> 1 -> 0 in LDS.  Arithmetic
 // order as in the separate kernels.  G leaves without its chain factor (kFoldScale).
 __global__ void __launch_bounds__(256)
-k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
+k_blur_stats_gimage_gm(const float *__restrict__ in0, int64_t in_stride, int H, int W, ImgArgs ia, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
                        float4 *__restrict__ zero_extra, int64_t n_extra4) {
     constexpr int TH = kGmTileH, TW = kGmTileW;
-    const float *__restrict__ img = ia.in[blockIdx.y];
+    const float *__restrict__ img = in0 + blockIdx.y * in_stride;  // (leading, preloaded arguments: the tile loads leave without waiting for the argument block)
     float *__restrict__ blurred = ia.blurred[blockIdx.y];
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     float *__restrict__ G = ia.G[blockIdx.y];
@@ -1134,7 +1136,7 @@ k_blur_stats_gimage_gm(ImgArgs ia, int H, int W, float k0, float k1, int omit, i
 constexpr int kMuLines = 32;                       // accumulators of K1's sum (same-line atomics serialise: one line each)
 constexpr int kMuStride = kMuLines * kSubStride;   // doubles per reference time
 __global__ void __launch_bounds__(256)
-k_blur_stats_adj_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
+k_blur_stats_adj_var(const float *__restrict__ in0, int64_t in_stride, int H, int W, ImgArgs ia, float k0, float k1, int omit, int nsub, double *__restrict__ stat_base,
                      float4 *__restrict__ zero_extra, int64_t n_extra4, const double *__restrict__ musum, double *__restrict__ musum_next,
                      int64_t n_events) {
     constexpr int TH = 8, TW = 32;
@@ -1147,7 +1149,7 @@ k_blur_stats_adj_var(ImgArgs ia, int H, int W, float k0, float k1, int omit, int
         if (blockIdx.x == 0 && threadIdx.x < kMuLines)
             __hip_atomic_store(&musum_next[blockIdx.y * kMuStride + threadIdx.x * kSubStride], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const float *__restrict__ img = ia.in[blockIdx.y];
+    const float *__restrict__ img = in0 + blockIdx.y * in_stride;  // (leading, preloaded arguments: the tile loads leave without waiting for the argument block)
     float *__restrict__ blurred = ia.blurred[blockIdx.y];
     float *__restrict__ zero_img = ia.zero[blockIdx.y];
     float *__restrict__ G = ia.G[blockIdx.y];
@@ -1593,6 +1595,9 @@ k_finish_lines(const double *__restrict__ raw, int n_ref, double *__restrict__ g
 // the event kernels, once per workgroup size
 namespace cmax {
 #define CMAX_SLOTS 2048
+#define CMAX_WINCAP 8192
+#define CMAX_ACC_TILES 3
+#define CMAX_ACC_SMALL_GROUPS 3
 #define CMAX_THREADS 256
 #define CMAX_EVENT_NS t256
 #include "cmax_event_kernels.inc"
@@ -1608,9 +1613,29 @@ namespace cmax {
 #include "cmax_event_kernels.inc"
 #undef CMAX_THREADS
 #undef CMAX_EVENT_NS
+// mid segments (3064 events, four source tiles wide: cmax_handle_s::mid): 512 threads x 6 events
+#undef CMAX_SLOTS
+#undef CMAX_WINCAP
+#undef CMAX_ACC_TILES
+#undef CMAX_ACC_SMALL_GROUPS
+#define CMAX_SLOTS 3072
+#define CMAX_WINCAP 6144
+#define CMAX_ACC_TILES 4
+#define CMAX_ACC_SMALL_GROUPS 5
+#define CMAX_THREADS 512
+#define CMAX_EVENT_NS m512
+#include "cmax_event_kernels.inc"
+#undef CMAX_THREADS
+#undef CMAX_EVENT_NS
 // big segments (4088 events: cmax_handle_s::big): 512 threads x 8 events, 1024 x 4
 #undef CMAX_SLOTS
+#undef CMAX_WINCAP
+#undef CMAX_ACC_TILES
+#undef CMAX_ACC_SMALL_GROUPS
 #define CMAX_SLOTS 4096
+#define CMAX_WINCAP 8192
+#define CMAX_ACC_TILES 6
+#define CMAX_ACC_SMALL_GROUPS 3
 #define CMAX_THREADS 512
 #define CMAX_EVENT_NS b512
 #include "cmax_event_kernels.inc"
@@ -1622,6 +1647,9 @@ namespace cmax {
 #undef CMAX_THREADS
 #undef CMAX_EVENT_NS
 #undef CMAX_SLOTS
+#undef CMAX_WINCAP
+#undef CMAX_ACC_TILES
+#undef CMAX_ACC_SMALL_GROUPS
 
 __global__ void k_empty(const int4 *) {}  // cmax_debug_launch_floor
 
@@ -1703,8 +1731,10 @@ k_finish_deferred(ObjParams op, const double *__restrict__ stat, const double *_
 // flag / seq (cmax_objective_host): result and gtheta are PINNED HOST memory; after they are visible system-wide the kernel writes
 // the run counter `seq` behind them, which the host polls -- no copy engine, no hipStreamQuery.
 __global__ void __launch_bounds__(64)
-k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__restrict__ raw, double *__restrict__ result, double *__restrict__ gtheta,
+k_finish_raw(const double *__restrict__ raw, int n_ref, ObjParams op, const double *__restrict__ stat, double *__restrict__ result, double *__restrict__ gtheta,
              volatile unsigned long long *flag = nullptr, unsigned long long seq = 0) {
+    // (raw and n_ref lead the parameter list: they arrive in SGPRs -- kernel-argument preload -- and the loads below leave at once, while
+    // everything finalize_deferred needs is fetched from the argument block beside them: one round trip less in a one-wave kernel)
     const int lane = threadIdx.x;
     double v[4][6];
     // every lane loads ITS line's six doubles as three 16-byte loads, all issued before the first use (lanes >= kRawLines re-read
@@ -1716,7 +1746,7 @@ k_finish_raw(ObjParams op, const double *__restrict__ stat, const double *__rest
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) v[k][q] = 0.0;
-        if (k < op.n_ref) {  // uniform
+        if (k < n_ref) {  // uniform
             const double2_v *src = reinterpret_cast<const double2_v *>(raw + (int64_t)k * kRawStride + line * kSubStride);
             const double2_v a = src[0], b = src[1], c = src[2];
             v[k][0] = a.x;
@@ -1791,6 +1821,9 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
         if (h->big) {  // the work list holds segments of up to 4088 events: only the big-segment kernels can run it
             if (h->has_frac) CMAX_LAUNCH_VOTE(b512, true);
             else CMAX_LAUNCH_VOTE(b512, false);
+        } else if (h->mid) {  // ... of up to 3064 events
+            if (h->has_frac) CMAX_LAUNCH_VOTE(m512, true);
+            else CMAX_LAUNCH_VOTE(m512, false);
         } else if (force ? force == 512 : h->nseg > 512) {  // as for K3: cfg2 (704 half-tile segments) K1 6.35 -> 5.97 us, evaluation 18.06 -> 17.38
             if (h->has_frac) CMAX_LAUNCH_VOTE(t512, true);
             else CMAX_LAUNCH_VOTE(t512, false);
@@ -1806,6 +1839,7 @@ static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 static int grad_threads(const cmax_handle_s *h, int model) {
     static const int force = forced_ns("CMAX_GRAD_NS");
     if (h->big) return model == CMAX_MODEL_VOXEL ? 1024 : 512;
+    if (h->mid) return 512;
     if (model == CMAX_MODEL_VOXEL && h->small_acc && h->owned && !force) return 512;
     if (force ? (force == 1024 && model == CMAX_MODEL_VOXEL) : (model == CMAX_MODEL_VOXEL && wide_groups(h))) return 1024;
     return (force ? force >= 512 : h->nseg > 512) ? 512 : 256;
@@ -1825,6 +1859,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
 #define CMAX_LAUNCH_DET(FRAC, FOLD)                                                                                                         \
     do {                                                                                                                                    \
         if (h->big) hipLaunchKernelGGL((b512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(b512::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
+        else if (h->mid) hipLaunchKernelGGL((m512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(m512::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
         else hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
     } while (0)
         if (h->has_frac) {
@@ -1855,7 +1890,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
             }                                                                 \
         } else if constexpr (MODEL == CMAX_MODEL_VOXEL) {                     \
             if (owned && small) {                                             \
-                if constexpr (NS::kThr == 512 && !NS::kBig) { CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwnedSmall); } \
+                if constexpr (NS::kThr == 512 && NS::kSlots <= 3072) { CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwnedSmall); } \
             } else if (owned) {                                               \
                 CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, kGradOwned);               \
             } else {                                                          \
@@ -1869,7 +1904,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     if (fold == kFoldDeferred) {                                                             \
         if constexpr (MODEL == CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); } \
     } else if (fold == kFoldStatsInside) {                                                   \
-        if constexpr (MODEL == CMAX_MODEL_VOXEL && NS::kThr == 512 && !NS::kBig) {           \
+        if constexpr (MODEL == CMAX_MODEL_VOXEL && NS::kThr == 512 && NS::kSlots <= 3072) {   \
             if (small) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwnedSmall); } \
             else { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); }            \
         } else if constexpr (MODEL != CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); } \
@@ -1896,6 +1931,8 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
             } else {
                 CMAX_LAUNCH_GRAD_NS(b512)
             }
+        } else if (h->mid) {  // ... of up to 3064 events
+            CMAX_LAUNCH_GRAD_NS(m512)
         } else if (small) {
             CMAX_LAUNCH_GRAD_NS(t512)
         } else if (force ? (force == 1024 && MODEL == CMAX_MODEL_VOXEL) : (MODEL == CMAX_MODEL_VOXEL && wide_groups(h))) {  // measured: voxel K3 of cfg4 22.1 us (512 threads) -> 19.3 us
@@ -1994,7 +2031,7 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
     CMAX_CHECK_LAUNCH();
     if (det) {  // exact integer sums -> fp32 images, one rounding each; the integer images are zero again afterwards
         FixedArgs fa = {};
-        fa.inv_fix = h->big ? 1.0 / 524288.0 : 1.0 / 1048576.0;
+        fa.inv_fix = (h->big || h->mid) ? 1.0 / 524288.0 : 1.0 / 1048576.0;
         for (int k = 0; k < n_ref; ++k) {
             fa.src[k] = ra.img64[k];
             fa.dst[k] = imgs[k];
@@ -2197,6 +2234,14 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         }
         return cnt;
     };
+    // MID segments (round 4; CMAX_MID_SEG=0 / 1 overrides for A/B runs): 3064 events, four source tiles or five well-filled (tile, bin)
+    // groups wide.  A launch of more workgroups than the chip holds at once (256 CUs x 4 workgroups of 512 threads) runs in rounds, and
+    // every round pays the ~2.5 us a workgroup waits for its first loads again (tools/timeline.py): the standard cut of cfg5's shard is
+    // 1693 workgroups -- two rounds, the second two thirds full -- this one 900 in ONE round; cfg4: 1258 -> 748.  Taken when it fits one
+    // round where the standard cut does not.
+    static const int mid_env = getenv("CMAX_MID_SEG") ? atoi(getenv("CMAX_MID_SEG")) : -1;
+    constexpr int kResidentGroups = 1024;  // workgroups of 512 threads the chip holds at once
+    h->mid = false;
     if (big_env >= 0) {
         h->big = big_env != 0;
     } else if (h->n >= (int64_t)8000000) {
@@ -2208,8 +2253,12 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         const int std_n = owned_count(kSegMax, T == 1 ? 3 : (small_std ? kAccCellsDense / 256 : kAccCells / 256));
         const int big_n = std_n >= 0 ? owned_count(4088, T == 1 ? 6 : kAccCells / 256) : -1;
         h->big = std_n >= 0 ? (int64_t)std_n * 4 >= (int64_t)big_n * 11 : h->n >= (int64_t)4000000;
+        if (!h->big && mid_env != 0 && !getenv("CMAX_NO_OWNED")) {
+            const int mid_n = owned_count(3064, T == 1 ? 4 : (small_std ? 5 : kAccCells / 256));
+            h->mid = mid_env > 0 ? mid_n > 0 : (mid_n > 0 && mid_n <= kResidentGroups && std_n > kResidentGroups);
+        }
     }
-    h->seg_max = h->big ? 4088 : kSegMax;
+    h->seg_max = h->big ? 4088 : (h->mid ? 3064 : kSegMax);
     const int kSegCut = h->seg_max;
     int max_groups = T == 1 ? 3 : kAccCells / 256;
     static const int free_env = getenv("CMAX_FREE_CUT") ? atoi(getenv("CMAX_FREE_CUT")) : -1;  // tuning only
@@ -2238,8 +2287,14 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // with 2 (the per-thread fixed costs of K3 are spread over twice the events).  CMAX_SMALL_ACC=0 / 1 overrides (A/B runs).
     static const int small_env = getenv("CMAX_SMALL_ACC") ? atoi(getenv("CMAX_SMALL_ACC")) : -1;
     h->small_acc = T > 1 && h->owned && !h->big && (small_env >= 0 ? small_env != 0 : h->n >= (int64_t)480 * ngroups);
+    if (h->mid && !h->owned) {  // (the mid layout exists for group-aligned work lists only: fall back to the standard cut)
+        h->mid = false;
+        h->seg_max = kSegMax;
+        set_error("build_segments: mid layout chosen for a work list that is not group-aligned");
+        return CMAX_ESTATE;
+    }
     if (h->owned) {
-        const int span_max = T == 1 ? (h->big ? 6 : 3) : (h->small_acc ? kAccCellsDense / 256 : kAccCells / 256), row_groups = h->ntc * T;  // dense: kAccCellsDense (x 2 for big segments)
+        const int span_max = T == 1 ? (h->big ? 6 : (h->mid ? 4 : 3)) : (h->small_acc ? (h->mid ? 5 : kAccCellsDense / 256) : kAccCells / 256), row_groups = h->ntc * T;  // dense: kAccCellsDense (x 2 for big segments)
         for (int r0 = 0; r0 < ngroups; r0 += row_groups) {
             h->row_seg_start.push_back((int)segs.size());
             int g = r0;
@@ -2830,7 +2885,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     if (fused_bv) {
         ProfScope prof(h, kProfStats, s);
         for (int rep = 0; rep < h->prof_repeat; ++rep)
-            hipLaunchKernelGGL(k_blur_stats_adj_var, gm_grid, dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary, op.nsub,
+            hipLaunchKernelGGL(k_blur_stats_adj_var, gm_grid, dim3(256), 0, s, ia.in[0], npix, Hp, Wp, ia, (float)k0, (float)k1, d->omit_boundary, op.nsub,
                                h->d_stat, clear4, nclear4, h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride,
                                h->d_musum + (int64_t)(h->mu_buf ^ 1) * 4 * kMuStride, h->n);
         CMAX_CHECK_LAUNCH();
@@ -2839,7 +2894,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     } else if (blur_var) {
         ProfScope prof(h, kProfStats, s);
         for (int rep = 0; rep < h->prof_repeat; ++rep)
-            hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h), d->n_ref), dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary,
+            hipLaunchKernelGGL(k_blur_stats_var, dim3(stat_blocks(h), d->n_ref), dim3(256), 0, s, ia.in[0], npix, Hp, Wp, ia, (float)k0, (float)k1, d->omit_boundary,
                                op.nsub, h->d_stat, clear4, nclear4);
         CMAX_CHECK_LAUNCH();
     } else if (!(deferred || fused_gm || stats_inside)) {  // those get their statistics from K3 / from the fused image kernel below
@@ -2920,10 +2975,10 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         ProfScope prof(h, kProfStats, s);
         for (int rep = 0; rep < h->prof_repeat; ++rep) {
             if (d->sigma > 0)  // raw votes -> blurred image, statistics and the finished G (blur transpose included)
-                hipLaunchKernelGGL(k_blur_stats_gimage_gm, gm_grid, dim3(256), 0, s, ia, Hp, Wp, (float)k0, (float)k1, d->omit_boundary, op.nsub,
+                hipLaunchKernelGGL(k_blur_stats_gimage_gm, gm_grid, dim3(256), 0, s, ia.in[0], npix, Hp, Wp, ia, (float)k0, (float)k1, d->omit_boundary, op.nsub,
                                    h->d_stat, clear4, nclear4);
             else
-                hipLaunchKernelGGL(k_stats_gimage_gm, gm_grid, dim3(256), 0, s, ia, Hp, Wp, d->omit_boundary, op.nsub, h->d_stat, clear4, nclear4);
+                hipLaunchKernelGGL(k_stats_gimage_gm, gm_grid, dim3(256), 0, s, ia.in[0], npix, Hp, Wp, ia, d->omit_boundary, op.nsub, h->d_stat, clear4, nclear4);
         }
         CMAX_CHECK_LAUNCH();
     }
@@ -2981,7 +3036,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             const int s0 = h->row_seg_start[tr0], s1 = h->row_seg_start[tr1];
             RefArgs rb = ra;
             rb.win += s0;  // (one reference time: the windows of segment i sit at win[i])
-            rb.shifts += (int64_t)s0 * (h->big ? 512 : 256);
+            rb.shifts += (int64_t)s0 * (h->big ? 512 : (h->mid ? 384 : 256));
             if (s1 > s0) launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, rb, d->n_ref, fold, op, nullptr, (float *)grad, b == 0 ? res : nullptr, owned, s, s0, s1 - s0);
             CMAX_CHECK_LAUNCH();
             rc = c2_exchange_band(h, c2_comm, (float *)grad, b, bands, s);
@@ -3016,7 +3071,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     } else if (deferred) {
         if (!raw_only) {
             ProfScope prof(h, kProfFinish, s);
-            hipLaunchKernelGGL(k_finish_raw, dim3(1), dim3(64), 0, s, op, h->d_stat, raw, result, (double *)grad, host_flag, host_seq);
+            hipLaunchKernelGGL(k_finish_raw, dim3(1), dim3(64), 0, s, (const double *)raw, op.n_ref, op, h->d_stat, result, (double *)grad, host_flag, host_seq);
             CMAX_CHECK_LAUNCH();
         }
     } else if (two_dof) {
@@ -3083,6 +3138,9 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
             if (h->big) {
                 if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan2<true>), grid, dim3(b512::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
                 else hipLaunchKernelGGL((b512::k_vote_tan2<false>), grid, dim3(b512::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
+            } else if (h->mid) {
+                if (h->has_frac) hipLaunchKernelGGL((m512::k_vote_tan2<true>), grid, dim3(m512::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
+                else hipLaunchKernelGGL((m512::k_vote_tan2<false>), grid, dim3(m512::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
             } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan2<true>), grid, dim3(t256::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
             else hipLaunchKernelGGL((t256::k_vote_tan2<false>), grid, dim3(t256::kThr), 0, s, h->d_segs, h->nseg, ev, wp, ra);
         }
@@ -3432,6 +3490,9 @@ static void launch_vote_tan(cmax_handle_s *h, const EvView &ev, const WarpParams
     if (h->big) {
         if (h->has_frac) hipLaunchKernelGGL((b512::k_vote_tan<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
         else hipLaunchKernelGGL((b512::k_vote_tan<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
+    } else if (h->mid) {
+        if (h->has_frac) hipLaunchKernelGGL((m512::k_vote_tan<MODEL, true>), grid, dim3(m512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
+        else hipLaunchKernelGGL((m512::k_vote_tan<MODEL, false>), grid, dim3(m512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
     } else if (h->has_frac) hipLaunchKernelGGL((t256::k_vote_tan<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
     else hipLaunchKernelGGL((t256::k_vote_tan<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, draw, h->d_stat_tan, draw64);
 }
@@ -3443,6 +3504,9 @@ static void launch_grad_hvp(cmax_handle_s *h, const EvView &ev, const WarpParams
     if (h->big) {
         if (h->has_frac) hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, true>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
         else hipLaunchKernelGGL((b512::k_grad_hvp<MODEL, false>), grid, dim3(b512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
+    } else if (h->mid) {
+        if (h->has_frac) hipLaunchKernelGGL((m512::k_grad_hvp<MODEL, true>), grid, dim3(m512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
+        else hipLaunchKernelGGL((m512::k_grad_hvp<MODEL, false>), grid, dim3(m512::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
     } else if (h->has_frac) hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, true>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
     else hipLaunchKernelGGL((t256::k_grad_hvp<MODEL, false>), grid, dim3(t256::kThr), 0, s, ev, wp, tp, h->d_segs, h->nseg, G, Gp, gpart, hflow, det);
 }
@@ -3850,7 +3914,7 @@ int cmax_debug_launch_floor(cmax_handle_t h, int pairs, cmax_stream_t stream) {
     CMAX_REQUIRE(h != nullptr && pairs > 0, "debug_launch_floor");
     CMAX_REQUIRE(h->n > 0 && h->nseg > 0, "debug_launch_floor: no events set");
     const dim3 grid(8 * ((h->nseg + 7) / 8));
-    const int k1 = h->big ? 512 : (h->nseg > 512 ? 512 : 256), k3 = grad_threads(h, CMAX_MODEL_2DOF);
+    const int k1 = (h->big || h->mid) ? 512 : (h->nseg > 512 ? 512 : 256), k3 = grad_threads(h, CMAX_MODEL_2DOF);
     for (int i = 0; i < pairs; ++i) {
         hipLaunchKernelGGL(k_empty, grid, dim3(k1), 0, (hipStream_t)stream, h->d_segs);
         hipLaunchKernelGGL(k_empty, grid, dim3(k3), 0, (hipStream_t)stream, h->d_segs);

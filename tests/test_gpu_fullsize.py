@@ -141,7 +141,8 @@ def test_cfg5_shard_full_size_with_gradient():
 WORK_LISTS = [
     # (tag, size, n, T, model, expected segment_events, expected small accumulators, segments above 1024?)
     ("voxel 1.7M 260x346: standard segments of 4 groups, 512-thread K3 with 12-group accumulators", (260, 346), 1_700_000, 10, "dense-flow-voxel", 2040, False, False),
-    ("voxel 3M 480x640: 8 groups per segment, more than 1024 segments -> 1024-thread K3", (480, 640), 3_000_000, 10, "dense-flow-voxel", 2040, False, True),
+    ("voxel 3M 480x640: 12 sparse groups per MID segment (1022 workgroups: one round), 512-thread K3 with 12-group accumulators", (480, 640), 3_000_000, 10, "dense-flow-voxel", 3064, False, False),
+    ("voxel 3.4M 480x640: 8 groups per standard segment, more than 1024 segments -> 1024-thread K3", (480, 640), 3_400_000, 10, "dense-flow-voxel", 2040, False, True),
     ("voxel 4M 260x346: one group per standard segment -> BIG segments of 3 groups, b1024 K3", (260, 346), 4_000_000, 10, "dense-flow-voxel", 4088, False, True),
     ("dense 4M 720p: one tile per standard segment -> BIG segments of 3 tiles, owned b512 K3", (720, 1280), 4_000_000, 0, "dense-flow", 4088, False, True),
     ("dense 3M 720p: two tiles per standard segment stay", (720, 1280), 3_000_000, 0, "dense-flow", 2040, False, True),
@@ -172,9 +173,10 @@ def test_work_list_variants_against_the_oracle(tag, size, n, Tn, model, seg_even
 
 def test_work_list_rule_on_the_bench_configurations():
     """cfg2 (2674 events per tile: not group-aligned, 1M events) keeps standard segments, cfg3 (4170 per tile, 5M events) gets big
-    ones, cfg4 (535 events per (tile, bin) group) the small accumulators, cfg5's shard (694 per tile) standard segments."""
-    cases = [((260, 346), 1_000_000, 0, 2040, False), ((480, 640), 5_000_000, 0, 4088, False), ((260, 346), 2_000_000, 10, 2040, True),
-             ((720, 1280), 2_500_000, 0, 2040, False)]
+    ones, cfg4 (535 events per (tile, bin) group) the small accumulators on MID segments (round 4: 748 workgroups of five groups in one
+    round instead of 1258 of three in two), cfg5's shard (694 per tile) mid segments of four tiles (900 instead of 1693)."""
+    cases = [((260, 346), 1_000_000, 0, 2040, False), ((480, 640), 5_000_000, 0, 4088, False), ((260, 346), 2_000_000, 10, 3064, True),
+             ((720, 1280), 2_500_000, 0, 3064, False)]
     for size, n, Tn, seg_events, small in cases:
         ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=46)
         info = E.CMaxHandle(size).set_events(ev, time_bin=Tn).work_list_info()
