@@ -73,6 +73,9 @@ WORKLOADS = {
     # results delivered TO THE HOST after every evaluation (cmax_objective_host: what a sequential optimiser sees)
     "cfg2_raw": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="raw",
                      desc="cfg2 through cmax_objective_raw: K1 + K3, 32 x 6 partial sums left on the device and folded by the consumer"),
+    "cfg2_batch8": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="batch", batch=8,
+                        desc="cfg2 through cmax_objective_batch: 8 candidate thetas per call, one launch of each kernel (blockIdx.z = candidate); "
+                             "ms_per_step and events/s are PER EVALUATION (8 per call)"),
     "cfg2_theta80": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, theta=(80.0, -50.0),
                          desc="cfg2 at a large motion: theta = (80, -50) px over the batch (windows of the source tiles' size + 80 x 50 px)"),
     # "dense F ~ U(-5, 5) per pixel *and* a smooth field" -- the per-pixel random flow of src/utils/flow_utils.py:20-30
@@ -325,7 +328,13 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     # "host": cmax_objective_host, every step waits for its numbers on the host (sequential: what one optimiser iteration costs).
     form = cfg.get("form") or args.form
     finalize = None
-    if form == "raw" and world == 1 and handle.has_raw(desc):
+    per_call = 1  # evaluations per call (cfg2_batch8: 8)
+    if form == "batch" and world == 1:
+        per_call = int(cfg["batch"])
+        thetas = np.asarray(motion, dtype=np.float64)[None, :] * np.linspace(0.6, 1.3, per_call)[:, None]  # a line search's steps along theta
+        call, res_b, grad_b = handle.prepare_batch(desc, torch.from_numpy(thetas).to(dev).float().contiguous())
+        res, grad = res_b[per_call // 2], grad_b
+    elif form == "raw" and world == 1 and handle.has_raw(desc):
         call, res, finalize = handle.prepare_raw(desc, motion_dev)
         grad, form = None, "raw"
     elif form == "host" and world == 1:
@@ -370,15 +379,16 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     elapsed = float(np.median(times))
     loss = float(finalize()[0][0]) if finalize else float(res[0].item() if hasattr(res[0], "item") else res[0])
     n_total = n_local * world
-
+    evals = steps * per_call  # evaluations per window (a batch call evaluates the objective per_call times): every figure below is per EVALUATION
     out = {"workload": cfg["desc"], "events_per_gpu": n_local, "events_total": n_total, "image": [H, W], "motion_model": cfg["model"],
            "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "time_bins": T,
-           "ms_per_step": elapsed / steps * 1e3, "value": n_total * steps / elapsed,
-           "window_ms_per_step": {"min": float(times[0]) / steps * 1e3, "median": elapsed / steps * 1e3, "max": float(times[-1]) / steps * 1e3,
-                                  "windows": windows, "steps_per_window": steps},
+           "ms_per_step": elapsed / evals * 1e3, "value": n_total * evals / elapsed,
+           "window_ms_per_step": {"min": float(times[0]) / evals * 1e3, "median": elapsed / evals * 1e3, "max": float(times[-1]) / evals * 1e3,
+                                  "windows": windows, "steps_per_window": evals},
            "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives, "deterministic": bool(args.deterministic),
            "result_form": {"raw": "raw sums on the device, folded by the consumer on the host (cmax_objective_raw + cmax_finalize_raw_host)",
                            "device": "loss + gradient on the device (cmax_objective)",
+                           "batch": "loss + gradient of every candidate on the device (cmax_objective_batch)",
                            "host": "loss + gradient on the host after every evaluation (cmax_objective_host)"}[form]}
     if world > 1:
         out["rccl"] = dict(zip(("nranks", "rank", "version"), handle.comm_info()))
@@ -388,7 +398,7 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     out["evaluation_GBps_per_gpu"] = eval_bytes / (out["ms_per_step"] * 1e-3) / 1e9
     out["evaluation_frac"] = out["evaluation_GBps_per_gpu"] / HBM_PEAK_GBS
 
-    if profile:
+    if profile and form != "batch":
         # instrumented passes (after the timed region, same inputs): HIP events recorded on the launch stream
         # around every launch of the kernel classes.
         #  (a) one launch per bracket: what an evaluation actually runs, but each bracket adds ~2.5 us of
@@ -596,7 +606,7 @@ def main():
         # N = 1: the other single-GPU configurations, cfg5 as BASELINE states it on ONE GPU (the N = 1 point of its strong-scaling
         # curve), a working set larger than the Infinity Cache, and the headline's second rows (blur; sharp image)
         names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_raw", "cfg2_host_result", "cfg2_sigma1", "cfg2_structured",
-                              "cfg2_theta80", "cfg3_rough", "cfg5_rough")
+                              "cfg2_theta80", "cfg2_batch8", "cfg3_rough", "cfg5_rough")
                   if w != args.workload]
                  if world == 1 else ["cfg5_strong"])
         for wname in names:

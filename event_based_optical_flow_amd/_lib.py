@@ -116,6 +116,7 @@ SIGNATURES = {
     "cmax_objective_raw": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp]),
     "cmax_finalize_raw_host": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp]),
     "cmax_objective_hvp": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
+    "cmax_objective_batch": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_int, c_vp, c_vp, c_vp]),
     "cmax_objective_hvp_dist": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_vote": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_objective_finish": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),

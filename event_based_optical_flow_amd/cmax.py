@@ -6,6 +6,7 @@ objective evaluation runs warp+vote -> contrast -> gather-gradient on the GPU wi
 materialising warped events.  `ContrastObjective` exposes it as a differentiable callable
 `loss = objective(motion)` for `scipy_autograd.minimize` / `torch.autograd.grad`.
 """
+import copy
 import ctypes
 import logging
 from typing import Dict, Optional, Sequence, Tuple, Union
@@ -312,6 +313,41 @@ class CMaxHandle:
         call.keepalive = (m, desc, raw, host)
         call.motion = m
         return call, raw, finalize
+
+    def prepare_batch(self, desc: CmaxObjective, motions):
+        """Prepared cmax_objective_batch call: (call, results, grads) for K candidate motions `motions` [K, ...] (2-DoF: [K, 2]; an
+        fp64 theta crosses the ABI in fp64 like in `evaluate`).  results float64 [K, 8], grads float64 [K, 2] | float32 [K, ...].
+        The reference's gradient-free paths evaluate batches of sampled motions (src/solver/base.py:738-758); for the 2-DoF
+        image-variance objective the K evaluations share one launch of each kernel (blockIdx.z = candidate)."""
+        mt = to_device_tensor(motions, "motions").detach()
+        K = int(mt.shape[0])
+        desc = CmaxObjective.from_buffer_copy(desc)
+        if desc.model == _lib.MODEL_2DOF and mt.dtype == torch.float64:
+            desc.motion_dtype = _lib.F64
+            m = mt.contiguous()
+        else:
+            desc.motion_dtype = _lib.F32
+            m = mt.to(torch.float32).contiguous()
+        results = torch.empty((K, 8), dtype=torch.float64, device=self.device)
+        if desc.model == _lib.MODEL_2DOF:
+            grads = torch.empty((K, 2), dtype=torch.float64, device=self.device)
+        else:
+            grads = torch.empty((K,) + tuple(m.shape[1:]), dtype=torch.float32, device=self.device)
+        fn, h, dref, mp, rp, gp, stream = self._lib.cmax_objective_batch, self._h, ctypes.byref(desc), m.data_ptr(), results.data_ptr(), grads.data_ptr(), F._stream
+
+        def call():
+            rc = fn(h, dref, mp, K, rp, gp, stream())
+            if rc:
+                check(rc)
+
+        call.keepalive = (m, desc, results, grads)
+        return call, results, grads
+
+    def evaluate_batch(self, desc: CmaxObjective, motions):
+        """(results [K, 8], grads [K, ...]) of K candidate motions: one cmax_objective_batch call."""
+        call, results, grads = self.prepare_batch(desc, motions)
+        call()
+        return results, grads
 
     def hvp(self, desc: CmaxObjective, motion, tangent) -> torch.Tensor:
         """Exact Hessian-vector product H @ tangent of the objective w.r.t. the motion (cmax_objective_hvp):

@@ -102,6 +102,10 @@ struct RefArgs {
     int4 *win;        // [n_ref][nseg] LDS windows: written by K1, read by K3 of the same evaluation (or null)
     unsigned *shifts; // [n_ref][nseg][kSlots / 8] cell offsets of the events K1 decided in fp64 (phase_warp), 8 slots per word; valid where Window::bmask says so
     int windows_only; // K1: publish the windows (and offsets) and return -- for a K3 whose vote this was not (cmax_objective_finish)
+    // cmax_objective_batch: blockIdx.z = candidate motion.  Element strides between consecutive candidates (0 for every other launch):
+    int64_t z_img;    // floats between their vote images (img[k] / zero[k] are candidate 0's)
+    int64_t z_raw;    // doubles between their raw-sum lines (stat[k] of K1, gpart of K3)
+    int z_motion;     // floats between their motions
     // K1, blurred variance with a gradient: sum_p I[p] B[p] (B = blur^T 1_Omega = b(r) b(c)) = the sum of the blurred image over
     // Omega, accumulated while the votes are flushed -- the image kernel then knows the mean before it has blurred anything
     double *musum[4];        // kMuLines accumulators (one 128-byte line each) per reference time, or null
@@ -188,6 +192,13 @@ struct cmax_handle_s {
     int *d_active = nullptr;  // [ntiles] source pixels that hold events, per tile (un-binned order; written by k_tile_sort)
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int4 *d_win = nullptr;        // [4][nseg] LDS windows of the last objective vote (K1 -> K3 of the same evaluation)
+    // cmax_objective_batch: K candidate motions per launch (allocated on first use, sized for batch_cap candidates)
+    float *bimg = nullptr;        // [2 buffers][batch_cap][n_ref <= 4][npix] vote images
+    double *braw = nullptr;       // [batch_cap][4][kRawStride] raw sums
+    int4 *bwin = nullptr;         // [batch_cap][4][nseg] windows
+    unsigned *bshifts = nullptr;  // [batch_cap][4][nseg][kShiftWordsMax]
+    int batch_cap = 0, batch_seg_cap = 0, batch_cur = 0;
+    int batch_zero[2] = {0, 0};  // the first batch_zero[b] images of buffer b are zero
     unsigned *d_shifts = nullptr; // [4][nseg][kShiftWordsMax] cell offsets of the events that vote decided in fp64 (RefArgs::shifts)
     // what those windows were computed for: K3 reuses them only for the same motion / model / reference times
     const float *win_motion = nullptr;
@@ -1735,6 +1746,10 @@ k_finish_raw(const double *__restrict__ raw, int n_ref, ObjParams op, const doub
              volatile unsigned long long *flag = nullptr, unsigned long long seq = 0) {
     // (raw and n_ref lead the parameter list: they arrive in SGPRs -- kernel-argument preload -- and the loads below leave at once, while
     // everything finalize_deferred needs is fetched from the argument block beside them: one round trip less in a one-wave kernel)
+    // blockIdx.x = candidate motion of cmax_objective_batch (one workgroup otherwise)
+    raw += (int64_t)blockIdx.x * n_ref * kRawStride;
+    result += 8 * blockIdx.x;
+    if (gtheta) gtheta += 2 * blockIdx.x;
     const int lane = threadIdx.x;
     double v[4][6];
     // every lane loads ITS line's six doubles as three 16-byte loads, all issued before the first use (lanes >= kRawLines re-read
@@ -1808,8 +1823,8 @@ static int forced_ns(const char *name) {
 }
 
 template <int MODEL>
-static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, hipStream_t s) {
-    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref);
+static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, hipStream_t s, int nz = 1) {
+    const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref, nz);  // z: candidate motions of cmax_objective_batch
     ProfScope prof(h, kProfVote, s);
 #define CMAX_LAUNCH_VOTE(NS, FRAC)                                                                                           \
     do {                                                                                                                    \
@@ -1850,10 +1865,10 @@ static int grad_threads(const cmax_handle_s *h, int model) {
 template <int MODEL>
 static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, int fold,
                         const ObjParams &op, double *gpart, float *gflow, double *result, bool owned, hipStream_t s, int seg0 = 0,
-                        int seg_n = -1) {
+                        int seg_n = -1, int nz = 1) {
     const int4 *segs = h->d_segs + seg0;
     const int nseg = seg_n < 0 ? h->nseg : seg_n;
-    const dim3 grid(8 * ((nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref);
+    const dim3 grid(8 * ((nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref, nz);
     ProfScope prof(h, kProfGrad, s);
     if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
 #define CMAX_LAUNCH_DET(FRAC, FOLD)                                                                                                         \
@@ -2350,6 +2365,10 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         dev_free(&h->d_gpart);
         dev_free(&h->d_win);
     dev_free(&h->d_shifts);
+    dev_free(&h->bimg);
+    dev_free(&h->braw);
+    dev_free(&h->bwin);
+    dev_free(&h->bshifts);
         dev_free(&h->d_shifts);
         int rc = dev_alloc(h, &h->d_segs, h->nseg);
         if (!rc) rc = dev_alloc(h, &h->d_win, (int64_t)4 * h->nseg);
@@ -3253,6 +3272,83 @@ int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *d, const void *
     if (rc) return rc;
     CMAX_REQUIRE(result, "objective_dist: result");
     return objective_eval(h, d, motion, result, grad, (hipStream_t)stream, h->comm);
+}
+
+// K candidate motions in ONE launch pair.  The reference's gradient-free paths evaluate the objective for batches of sampled motions
+// (src/solver/base.py:738-758 run_optuna; src/solver/patch_contrast_pyramid.py:363-415), and a line search asks for several steps
+// along one direction: each evaluation of such a batch alone is two dependent launches and a finishing one, and at cfg2's size those
+// launches' floor is 40 % of it (roofline.launch_floor_us).  Here blockIdx.z of K1 / K3 is the candidate -- every candidate its own
+// vote image, raw-sum lines and windows -- and the finishing kernel runs one wave per candidate.
+// Fast path: 2-DoF, plain image variance (sigma 0, not normalised), default mode, one GPU -- the headline objective.  Everything
+// else is evaluated candidate by candidate inside this call (same results, no speed-up).
+int cmax_objective_batch(cmax_handle_t h, const cmax_objective_t *d, const void *motions_v, int K, double *results, void *grads,
+                         cmax_stream_t stream) {
+    const float *motions = static_cast<const float *>(motions_v);
+    int rc = check_objective_args(h, d, motions);
+    if (rc) return rc;
+    CMAX_REQUIRE(results != nullptr && K >= 1 && K <= 64, "objective_batch: results / 1 <= K <= 64");
+    hipStream_t s = (hipStream_t)stream;
+    const bool two_dof = d->model == CMAX_MODEL_2DOF;
+    const int64_t gcount = two_dof ? 2 : (int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W;
+    const int64_t mfloats = two_dof ? (d->motion_dtype == CMAX_F64 ? 4 : 2) : gcount;  // floats per candidate motion
+    const size_t gbytes = two_dof ? 2 * sizeof(double) : (size_t)gcount * sizeof(float);
+    const bool fast = K > 1 && grads && deferred_applies(h, d, grads) && !d->normalized && !h->comm && !h->profiling;
+    if (!fast) {
+        for (int z = 0; z < K; ++z) {
+            rc = objective_eval(h, d, motions + z * mfloats, results + 8 * z, grads ? (char *)grads + (size_t)z * gbytes : nullptr, s, nullptr);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    const int64_t npix = (int64_t)h->Hp * h->Wp;
+    const int nr = d->n_ref;
+    if (K > h->batch_cap || h->nseg > h->batch_seg_cap) {
+        CMAX_CHECK_HIP(hipStreamSynchronize(s));
+        dev_free(&h->bimg);
+        dev_free(&h->braw);
+        dev_free(&h->bwin);
+        dev_free(&h->bshifts);
+        const int cap = std::max(K, h->batch_cap), scap = std::max(h->nseg, h->batch_seg_cap);
+        rc = dev_alloc(h, &h->bimg, (int64_t)2 * cap * 4 * npix);
+        if (!rc) rc = dev_alloc(h, &h->braw, (int64_t)cap * 4 * kRawStride);
+        if (!rc) rc = dev_alloc(h, &h->bwin, (int64_t)cap * 4 * scap);
+        if (!rc) rc = dev_alloc(h, &h->bshifts, (int64_t)cap * 4 * scap * kShiftWordsMax);
+        if (rc) return rc;
+        h->batch_cap = cap;
+        h->batch_seg_cap = scap;
+        h->batch_zero[0] = h->batch_zero[1] = 0;
+    }
+    // candidate z, reference time k: image at bimg[buffer][(z * nr + k) * npix]; the launch's images are contiguous
+    float *cur = h->bimg + (int64_t)h->batch_cur * h->batch_cap * 4 * npix;
+    float *nxt = h->bimg + (int64_t)(h->batch_cur ^ 1) * h->batch_cap * 4 * npix;
+    if (h->batch_zero[h->batch_cur] < K * nr) CMAX_CHECK_HIP(hipMemsetAsync(cur, 0, (size_t)K * nr * npix * sizeof(float), s));
+    const ObjParams op = obj_params(h, d);
+    const EvView ev = ev_view(h);
+    const WarpParams wp = warp_params(h, motions, 0, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
+    RefArgs ra = {};
+    ra.win = h->bwin;
+    ra.shifts = h->bshifts;
+    ra.z_img = (int64_t)nr * npix;
+    ra.z_raw = (int64_t)nr * kRawStride;
+    ra.z_motion = (int)mfloats;
+    for (int k = 0; k < nr; ++k) {
+        ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.img[k] = cur + k * npix;
+        ra.stat[k] = h->braw + (int64_t)k * kRawStride;  // K1's first workgroup of every (candidate, reference time) resets its lines
+        ra.zero[k] = nxt + k * npix;                      // K3 clears the other buffer's image of the same (candidate, reference time)
+    }
+    ra.n_events = h->n;
+    launch_vote<CMAX_MODEL_2DOF>(h, ev, wp, ra, nr, s, K);
+    CMAX_CHECK_LAUNCH();
+    launch_grad<CMAX_MODEL_2DOF>(h, ev, wp, ra, nr, kFoldDeferred, op, h->braw, nullptr, nullptr, false, s, 0, -1, K);
+    CMAX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_finish_raw, dim3(K), dim3(64), 0, s, (const double *)h->braw, nr, op, h->d_stat, results, (double *)grads,
+                       (volatile unsigned long long *)nullptr, 0ull);
+    CMAX_CHECK_LAUNCH();
+    h->batch_zero[h->batch_cur] = 0;           // holds votes now
+    h->batch_zero[h->batch_cur ^ 1] = K * nr;  // K3 cleared the first K * nr images of the other buffer (a larger batch clears it itself)
+    h->batch_cur ^= 1;
+    return 0;
 }
 
 int cmax_objective_has_raw(cmax_handle_t h, const cmax_objective_t *d) {

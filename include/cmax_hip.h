@@ -246,6 +246,17 @@ int cmax_objective(cmax_handle_t h, const cmax_objective_t *desc_host, const voi
 int cmax_objective_host(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion, double *result_host,
                         void *grad_host, cmax_stream_t stream);
 
+/* K candidate motions in one call (the reference's gradient-free paths evaluate the objective for batches of sampled motions:
+ * src/solver/base.py:738-758 run_optuna, src/solver/patch_contrast_pyramid.py:363-415; a line search asks for several steps along one
+ * direction).  motions: K consecutive motions as cmax_objective takes one (fp32 theta[2] | double theta[2] with motion_dtype CMAX_F64 |
+ * flow[2,H,W] | voxel[T,2,H,W]); results: device double[K][8]; grads: device double[K][2] (2DOF) or fp32 [K][...] (NULL: values only).
+ * For the 2-DoF image-variance objective (sigma 0, not normalised, default mode, no communicator) the K evaluations share ONE
+ * launch of each kernel: blockIdx.z is the candidate -- its own vote image, sums and windows -- so the launch structure that is 40 %
+ * of a single 1M-event evaluation is paid once per batch.  Every other objective is evaluated candidate by candidate inside the call
+ * (same results).  1 <= K <= 64; the handle keeps 2 K vote images for it.                                                       */
+int cmax_objective_batch(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motions, int K, double *results,
+                         void *grads, cmax_stream_t stream);
+
 /* Raw form of the 2-DoF objectives (default mode, non-empty batch; cmax_objective_has_raw says whether a descriptor on the
  * current batch qualifies -- everything 2-DoF except a NORMALISED plain variance, whose fold needs device-side statistics).
  * cmax_objective ends such an evaluation with a one-wave kernel that only adds up what the gathering kernel left and divides a

@@ -405,3 +405,36 @@ def test_voxel_chain_second_order_against_difference_quotients(scheme, t0):
     assert (gF - g0).abs().max().item() <= 1e-12 * g0.abs().max().item()
     fd2 = (adj(f + eps * df, gV) - adj(f - eps * df, gV)) / (2 * eps) + adj(f, dgV)
     assert (dgF - fd2).abs().max().item() <= 2e-6 * fd2.abs().max().item()
+
+
+def test_two_dof_sources_in_the_outer_padding_vote_like_the_reference():
+    """VERDICT r3 #8.  The reference's 2-DoF warp has no bounds check on the SOURCE (src/warp.py:506-520) and bilinear_vote masks per
+    corner of the TARGET (src/event_image_converter.py:355-372): with outer_padding > 0 an event whose source lies in the pad -- or
+    further out, if the motion brings it in -- still votes.  The leaf operators (Warp + EventImageConverter) keep exactly that
+    (against the oracle's restatement of those lines); the fused path cannot pack such events and says so: the pyramid solver hands
+    its batches over with on_dropped="raise" (solver/pyramid.py)."""
+    import torch
+
+    size, pad, n = (40, 52), 6, 6000
+    rng = np.random.default_rng(12)
+    ev = np.stack([rng.uniform(-5.0, size[0] + 5.0, n).round(), rng.uniform(-5.0, size[1] + 5.0, n).round(), np.sort(rng.uniform(0, 0.05, n)),
+                   rng.integers(0, 2, n).astype(np.float64)], axis=1)
+    ev[:40, 0] = -30.0  # far outside: comes in only through the motion
+    theta = np.array([31.0, -4.0])
+    off = ((ev[:, 0] < 0) | (ev[:, 0] >= size[0]) | (ev[:, 1] < 0) | (ev[:, 1] >= size[1])).sum()
+    assert off > 500
+    warped_ref, _ = orc.warp_event(ev, theta, "2d-translation", "first", size)
+    iwe_ref = orc.create_iwe(warped_ref, size, outer_padding=pad, sigma=0)
+    warp = E.Warp(size, normalize_t=True)
+    imager = E.EventImageConverter(size, outer_padding=pad)
+    warped, _ = warp.warp_event(torch.from_numpy(ev).cuda(), torch.from_numpy(theta).cuda(), "2d-translation", direction="first")
+    iwe = imager.create_iwe(warped, method="bilinear_vote", sigma=0).cpu().numpy()
+    assert iwe.shape == iwe_ref.shape == (size[0] + 2 * pad, size[1] + 2 * pad)
+    np.testing.assert_allclose(iwe, iwe_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(iwe_ref).max()))
+    # ... votes of off-sensor sources are in there: the image without them differs
+    keep = (ev[:, 0] >= 0) & (ev[:, 0] < size[0]) & (ev[:, 1] >= 0) & (ev[:, 1] < size[1])
+    iwe_on = orc.create_iwe(orc.warp_event(ev[keep], theta, "2d-translation", "first", size)[0], size, outer_padding=pad, sigma=0)
+    assert np.abs(iwe_ref - iwe_on).max() > 0.5
+    # the fused path refuses such a batch when asked to (what the solver asks for) instead of dropping the events silently
+    with pytest.raises(ValueError):
+        E.CMaxHandle(size, pad).set_events(ev, on_dropped="raise")
