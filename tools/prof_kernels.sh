@@ -22,9 +22,9 @@ with open(out + "/kernel_stats.txt", "w") as f:
     for k, v in rows:
         f.write("%-96s %6d %9.2f %9.2f %9.2f %11.1f\n" % (k[:96], len(v), sum(v) / len(v), min(v), max(v), sum(v)))
 import re
-hot = [(k, v) for k, v in rows if re.search(r"cmax::(?:[tb]\d+::)?k_", k) and len(v) >= 20 or "fillBuffer" in k]
+hot = [(k, v) for k, v in rows if re.search(r"cmax::(?:[tbm]\d+::)?k_", k) and len(v) >= 20 or "fillBuffer" in k]
 import re
-print("[%s] " % tag + "  ".join("%s %.2f" % (re.search(r"cmax::(?:[tb]\d+::)?(k_\w+)", k).group(1) if "cmax" in k else "memset", sum(v) / len(v)) for k, v in hot))
+print("[%s] " % tag + "  ".join("%s %.2f" % (re.search(r"cmax::(?:[tbm]\d+::)?(k_\w+)", k).group(1) if "cmax" in k else "memset", sum(v) / len(v)) for k, v in hot))
 import json
 for line in open(out + "/bench.log"):
     if line.startswith("{"):

@@ -23,8 +23,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     for k, v in d.items():
         import re
-        if re.search(r"cmax::(?:[tb]\d+::)?k_", k) and len(v) >= 10:
-            name = re.search(r"cmax::(?:[tb]\d+::)?(k_\w+)", k).group(1)
+        if re.search(r"cmax::(?:[tbm]\d+::)?k_", k) and len(v) >= 10:
+            name = re.search(r"cmax::(?:[tbm]\d+::)?(k_\w+)", k).group(1)
             res.setdefault(name, {})[ctr] = sum(v) / len(v)
 print(json.dumps(res, indent=1))
 json.dump(res, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1)

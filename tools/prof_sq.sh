@@ -27,7 +27,7 @@ for p in (1, 2, 3):
     for row in csv.DictReader(open(files[0])):
         d[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, ctrs in d.items():
-        m = re.search(r"cmax::(?:([tb]\d+)::)?(k_\w+)", k)
+        m = re.search(r"cmax::(?:([tbm]\d+)::)?(k_\w+)", k)
         if not m:
             continue
         name = (m.group(1) + "::" if m.group(1) else "") + m.group(2)
