@@ -76,8 +76,11 @@ WORKLOADS = {
     "cfg2_batch8": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="batch", batch=8,
                         desc="cfg2 through cmax_objective_batch: 8 candidate thetas per call, one launch of each kernel (blockIdx.z = candidate); "
                              "ms_per_step and events/s are PER EVALUATION (8 per call)"),
-    "cfg2_theta80": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, theta=(80.0, -50.0),
-                         desc="cfg2 at a large motion: theta = (80, -50) px over the batch (windows of the source tiles' size + 80 x 50 px)"),
+    "cfg2_theta80": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, theta=(80.0, -50.0), slabs=4,
+                         desc="cfg2 at a large motion: theta = (80, -50) px over the batch, events in 4 time slabs (cmax_set_time_slabs: "
+                              "windows of the source tiles' size + 20 x 13 px)"),
+    "cfg2_theta150": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, theta=(150.0, -100.0), slabs=4,
+                          desc="cfg2 at the search range of configs/*.yaml: theta = (150, -100) px over the batch, events in 4 time slabs"),
     # "dense F ~ U(-5, 5) per pixel *and* a smooth field" -- the per-pixel random flow of src/utils/flow_utils.py:20-30
     "cfg3_rough": dict(H=480, W=640, n=5_000_000, model="dense-flow", cost="gradient_magnitude", sigma=0.0, rough=5.0,
                        desc="cfg3 with a per-pixel random flow F ~ U(-5, 5): 5M events, 640x480, dense flow, gradient_magnitude"),
@@ -307,6 +310,8 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sliced.set_local_events(ev_dev, time_bin=T, device=dev)
+    if cfg.get("slabs"):
+        handle.set_time_slabs(cfg["slabs"])  # large motions: slab-major order (a second pass of the counting sort)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t0) * 1e3  # once per batch: pack + counting sort + work list (not in `value`)
     del ev_dev
@@ -606,7 +611,7 @@ def main():
         # N = 1: the other single-GPU configurations, cfg5 as BASELINE states it on ONE GPU (the N = 1 point of its strong-scaling
         # curve), a working set larger than the Infinity Cache, and the headline's second rows (blur; sharp image)
         names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_raw", "cfg2_host_result", "cfg2_sigma1", "cfg2_structured",
-                              "cfg2_theta80", "cfg2_batch8", "cfg3_rough", "cfg5_rough")
+                              "cfg2_theta80", "cfg2_theta150", "cfg2_batch8", "cfg3_rough", "cfg5_rough")
                   if w != args.workload]
                  if world == 1 else ["cfg5_strong"])
         for wname in names:

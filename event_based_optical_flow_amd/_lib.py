@@ -109,6 +109,7 @@ SIGNATURES = {
     "cmax_destroy": (c_int, [c_vp]),
     "cmax_set_events": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_dbl, c_dbl, c_int, c_vp]),
     "cmax_set_time_bins": (c_int, [c_vp, c_int, c_vp]),
+    "cmax_set_time_slabs": (c_int, [c_vp, c_int, c_vp]),
     "cmax_iwe": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_vp, c_vp]),
     "cmax_objective": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_host": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),

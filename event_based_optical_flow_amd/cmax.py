@@ -148,6 +148,22 @@ class CMaxHandle:
         check(self._lib.cmax_set_time_bins(self._h, int(time_bin), F._stream()))
         self.time_bin = int(time_bin)
 
+    def set_time_slabs(self, n_slab: int):
+        """Large motions of a 2-DoF / dense objective: order the batch in `n_slab` time slabs (cmax_set_time_slabs); <= 1 undoes it."""
+        check(self._lib.cmax_set_time_slabs(self._h, int(n_slab), F._stream()))
+        self.time_bin = 0
+        return self
+
+    def suggest_time_slabs(self, displacement_px: float) -> int:
+        """Slab count for a motion of up to `displacement_px` over the batch (profiles/r04_large_motion.txt: 1M events @346x260 --
+        none below ~25 px, 2 up to ~45 px, 4 beyond), capped so that a (tile, slab) group keeps >= ~600 events: smaller groups make
+        segments of three groups too short to pay for a workgroup."""
+        want = 1 if displacement_px < 25 else (2 if displacement_px < 45 else 4)
+        tiles = ((self.image_size[0] + 15) // 16) * ((self.image_size[1] + 15) // 16)
+        while want > 1 and self.n_events < 600 * tiles * want:
+            want //= 2
+        return want
+
     @property
     def n_events(self) -> int:
         n = ctypes.c_int64()

@@ -163,6 +163,7 @@ struct cmax_handle_s {
     int64_t n_dropped = 0;  // events of the last batch whose source pixel was off the sensor (or NaN): not packed
     bool has_frac = false;
     int n_time_bin = 0;
+    bool slab_major = false;  // the (tile, bin) groups are ordered (tile row, time slab, tile column): cmax_set_time_slabs (large motions)
     // packed, sorted events
     uint2 *evp = nullptr;  // packed events, 8 B each, 16-byte aligned base (+2 elements of padding)
     float *rx = nullptr, *ry = nullptr;
@@ -2173,8 +2174,11 @@ static int pinned_reserve(T **p, int64_t *cap, int64_t count) {
 // which moves events inside their groups and leaves the group starts alone (round 3: 0.16 -> see profiles, per 1M events)
 template <typename Overlap>
 static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchReadback *rb, Overlap overlap) {
-    const int T = stride == 1 ? h->n_time_bin : 1;  // groups per tile
-    const int ngroups = h->ntr * h->ntc * T;
+    // slab-major handles (cmax_set_time_slabs): the groups are (tile row, slab, tile column) -- ntr * S rows of ntc groups, one group per
+    // "tile" of that virtual grid; cut like an un-binned list, never owned (a source pixel belongs to S groups)
+    const bool slab = stride == 1 && h->slab_major && h->n_time_bin > 0;
+    const int T = (stride == 1 && !slab) ? h->n_time_bin : 1;  // groups per tile
+    const int ngroups = h->ntr * h->ntc * (slab ? h->n_time_bin : T);
     const int ntiles = h->ntr * h->ntc;
     const bool want_active = rb && h->n_time_bin == 0;
     // the pinned read-back mirrors the device allocation: [2 doubles] extremes | [4] flags | [ntiles] active pixels | [ngroups + 1] group starts
@@ -2257,7 +2261,9 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     static const int mid_env = getenv("CMAX_MID_SEG") ? atoi(getenv("CMAX_MID_SEG")) : -1;
     constexpr int kResidentGroups = 1024;  // workgroups of 512 threads the chip holds at once
     h->mid = false;
-    if (big_env >= 0) {
+    if (slab) {
+        h->big = false;
+    } else if (big_env >= 0) {
         h->big = big_env != 0;
     } else if (h->n >= (int64_t)8000000) {
         h->big = true;
@@ -2290,7 +2296,7 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // (LDS window) / kAccCells / 256 groups (LDS accumulators).  The flow-gradient kernel of a single-reference objective
     // then stores its groups' pixels instead of adding to them (k_grad, kGradOwned), and the buffer needs no clearing.
     h->owned = false;
-    if (h->n >= (int64_t)256 * kSegMax && !getenv("CMAX_NO_OWNED")) {
+    if (h->n >= (int64_t)256 * kSegMax && !getenv("CMAX_NO_OWNED") && !slab) {
         bool fits = true;
         for (int g = 0; g < ngroups && fits; ++g) fits = group_start[g + 1] - group_start[g] <= kSegCut;
         h->owned = fits;
@@ -2419,6 +2425,17 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
     hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, h->d_flags, stage);
     hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->d_active, h->d_flags, keys);
     CMAX_CHECK_LAUNCH();
+    if (T > 0 && h->slab_major) {  // slab-major group order (cmax_sort_kernels.h, S4b): final SoA -> staging SoA, the two swap roles
+        const int ngroups = ntiles * T;
+        hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(1024), 0, s, h->d_tile_start, ngroups, h->ntc, T, h->cursor);
+        hipLaunchKernelGGL(k_slab_regroup, dim3(ngroups), dim3(256), 0, s, h->d_tile_start, h->cursor, h->ntc, T, fin, stage, h->d_flags);
+        CMAX_CHECK_LAUNCH();
+        CMAX_CHECK_HIP(hipMemcpyAsync(h->d_tile_start, h->cursor, (size_t)(ngroups + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+        std::swap(h->evp, h->evp_alt);
+        std::swap(h->rx, h->rx_alt);
+        std::swap(h->ry, h->ry_alt);
+        std::swap(h->tau64, h->tau64_alt);
+    }
     static const bool run_sort = !getenv("CMAX_NO_RUN_SORT");
     BatchReadback rb;
     rb.n_in = n_in;
@@ -2640,13 +2657,27 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     CMAX_REQUIRE(h != nullptr, "set_time_bins: handle");
     CMAX_REQUIRE(n_time_bin >= 0 && n_time_bin <= 255, "set_time_bins: n_time_bin must be in 0..255");
-    if (n_time_bin == h->n_time_bin) return 0;
+    if (n_time_bin == h->n_time_bin && !h->slab_major) return 0;
     h->n_time_bin = n_time_bin;
+    h->slab_major = false;
     ++h->generation;
     if (h->n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // re-order the packed events in place (through the staging SoA); [0] "fractional sources" stays what it was
     return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, s);
+}
+
+int cmax_set_time_slabs(cmax_handle_t h, int n_slab, cmax_stream_t stream) {
+    CMAX_REQUIRE(h != nullptr, "set_time_slabs: handle");
+    CMAX_REQUIRE(n_slab >= 0 && n_slab <= 64, "set_time_slabs: n_slab must be in 0..64");
+    if (n_slab <= 1) n_slab = 0;  // one slab is the un-binned order
+    if (n_slab == 0 && !h->slab_major) return h->n_time_bin == 0 ? 0 : cmax_set_time_bins(h, 0, stream);
+    if (n_slab == h->n_time_bin && h->slab_major) return 0;
+    h->n_time_bin = n_slab;
+    h->slab_major = n_slab > 0;
+    ++h->generation;
+    if (h->n == 0) return 0;
+    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, (hipStream_t)stream);
 }
 
 int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac, int normalize_t,
@@ -2655,6 +2686,7 @@ int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mod
     CMAX_REQUIRE(model < 0 || motion != nullptr, "iwe: motion");
     CMAX_REQUIRE(model <= CMAX_MODEL_VOXEL, "iwe: model");
     CMAX_REQUIRE(model != CMAX_MODEL_VOXEL || (T > 0 && T == h->n_time_bin), "iwe: voxel T must match the handle's time bins");
+    CMAX_REQUIRE(model != CMAX_MODEL_VOXEL || !h->slab_major, "iwe: a voxel motion needs time BINS (cmax_set_time_bins), this handle is in slab order");
     hipStream_t s = (hipStream_t)stream;
     float *raw = sigma > 0 ? h->G : iwe_out;  // G is scratch outside cmax_objective
     int rc = vote_image(h, model, motion, T, ref_mode, ref_frac, normalize_t, raw, false, -1, s);
@@ -2687,6 +2719,7 @@ static int check_objective_args(cmax_handle_t h, const cmax_objective_t *d, cons
     CMAX_REQUIRE(d->motion_dtype == CMAX_F32 || (d->motion_dtype == CMAX_F64 && d->model == CMAX_MODEL_2DOF),
                  "objective: motion_dtype must be CMAX_F32, or CMAX_F64 for the 2-DoF model");
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || (d->T > 0 && d->T == h->n_time_bin), "objective: voxel T must match the handle's time bins");
+    CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || !h->slab_major, "objective: a voxel motion needs time BINS (cmax_set_time_bins), this handle is in slab order");
     CMAX_REQUIRE(!d->omit_boundary || (h->Hp > 2 && h->Wp > 2), "objective: image too small for omit_boundary");
     CMAX_REQUIRE((int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W * 4 < ((int64_t)1 << 32),
                  "objective: the motion field must be smaller than 4 GiB (32-bit byte offsets in the event kernels)");
@@ -3944,6 +3977,7 @@ int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h,
         if (rc) return rc;
         h->search_cap = n_patch;
     }
+    CMAX_REQUIRE(!h->slab_major, "patch_search: the handle is in slab order (cmax_set_time_slabs); the search walks tile-major groups");
     SearchArgs a;
     a.evp = h->evp;
     a.rx = h->rx;

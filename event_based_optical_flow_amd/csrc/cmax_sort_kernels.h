@@ -397,6 +397,56 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
     }
 }
 
+// S4b (time SLABS, round 4: cmax_set_time_slabs).  k_tile_sort leaves the (tile, bin) groups tile-major -- a tile's bins one after the
+// other: what the voxel gradient's accumulators want.  For LARGE MOTIONS of a 2-DoF or dense objective the groups are re-ordered
+// slab-major inside every tile row: (tile row, time slab, tile column).  Consecutive groups are then neighbouring tiles of ONE slab, a
+// segment of three of them spans 1/S of the batch's duration, and its LDS window is the tiles' extent plus 1/S of the displacement
+// range instead of all of it (150 px over the batch: the window no longer overflows; 80 px: a quarter of the cells to clear and flush).
+//   k_slab_offsets  one workgroup: new start of every group in slab-major order (exclusive scan of the group sizes in that order)
+//   k_slab_regroup  one workgroup per group: copies the group to its new place
+__device__ __forceinline__ int slab_old_group(int gnew, int ntc, int T) {  // (row, slab, col) -> (row, col, slab)
+    const int col = gnew % ntc, rs = gnew / ntc, slab = rs % T, row = rs / T;
+    return (row * ntc + col) * T + slab;
+}
+__global__ void __launch_bounds__(1024) k_slab_offsets(const int *__restrict__ old_start, int ngroups, int ntc, int T, int *__restrict__ new_start) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (ngroups + 1023) / 1024, b = t * per, e = min(b + per, ngroups);
+    int sum = 0;
+    for (int g = b; g < e; ++g) {
+        const int go = slab_old_group(g, ntc, T);
+        sum += old_start[go + 1] - old_start[go];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the per-thread totals
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = old_start[0] + part[t] - sum;
+    for (int g = b; g < e; ++g) {
+        const int go = slab_old_group(g, ntc, T);
+        new_start[g] = run;
+        run += old_start[go + 1] - old_start[go];
+    }
+    if (t == 1023) new_start[ngroups] = old_start[0] + part[1023];
+}
+__global__ void __launch_bounds__(256) k_slab_regroup(const int *__restrict__ old_start, const int *__restrict__ new_start, int ntc, int T, SortOut in, SortOut out,
+                                                      const int *__restrict__ flags) {
+    const bool frac = flags[0] != 0;
+    const int gnew = blockIdx.x, go = slab_old_group(gnew, ntc, T);
+    const int b = old_start[go], n = old_start[go + 1] - b, d = new_start[gnew];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        out.evp[d + i] = in.evp[b + i];
+        out.tau64[d + i] = in.tau64[b + i];
+        if (frac) {
+            out.rx[d + i] = in.rx[b + i];
+            out.ry[d + i] = in.ry[b + i];
+        }
+    }
+}
+
 // S5 (un-binned handles).  Inside a run of equal source pixel the tile sort leaves the events in the order its LDS atomics
 // happened to produce.  Ordering every run BY TIME puts events that warp to neighbouring places next to each other: K1 sums the
 // votes of consecutive events of a thread that fall into the same cell in registers before its LDS atomics, and with

@@ -195,6 +195,13 @@ int cmax_destroy(cmax_handle_t h);
 int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, int have_tminmax,
                     double tmin, double tmax, int n_time_bin, cmax_stream_t stream);
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream);
+/* LARGE MOTIONS of a 2-DoF / dense objective (round 4): re-order the batch into n_slab time slabs, slab-major inside every source
+ * tile row -- (tile row, slab, tile column) -- so that a segment's events span 1/n_slab of the batch's duration and its LDS window is
+ * the tiles' extent plus 1/n_slab of the displacement range (a window that would overflow at 150 px over the batch fits again; see
+ * DESIGN.md section 4 "large motions").  Results are those of the un-binned order (same events, same arithmetic; the sums are
+ * associated differently).  Voxel objectives and cmax_patch_search need cmax_set_time_bins order and refuse a slab handle;
+ * n_slab <= 1 returns to the un-binned order.  Blocks once like cmax_set_time_bins.                                              */
+int cmax_set_time_slabs(cmax_handle_t h, int n_slab, cmax_stream_t stream);
 
 /* Image of warped events for one reference time (fp32 [Hp,Wp], blurred if sigma > 0).
  * motion: fp32 theta[2] | flow[2,H,W] | voxel[T,2,H,W] in pixel per (normalised) time.

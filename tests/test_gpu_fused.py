@@ -322,6 +322,38 @@ def test_large_displacements_clip_the_lds_window(model):
     assert rel_max(grads[0], ref["grad"]) <= TOL
 
 
+@pytest.mark.parametrize("model", ["2d-translation", "dense-flow"])
+@pytest.mark.parametrize("slabs", [2, 4, 7])
+def test_time_slabs_large_displacement_parity(model, slabs):
+    """cmax_set_time_slabs: the batch in time slabs, slab-major inside a tile row -- a segment's window spans 1 / slabs of the
+    displacement range.  150 px over the batch (the search range of configs/*.yaml) against the oracle, every cost family that the
+    2-DoF / dense models take; and back to the un-binned order."""
+    size, n = (130, 173), 300_000
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=63)
+    if model == "2d-translation":
+        motion = np.array([150.0, -100.0])
+    else:
+        motion = E.utils.generate_smooth_flow(size, 150, grid=3, seed=64)
+    h = E.CMaxHandle(size).set_events(ev)
+    segs0 = h.work_list_info()["segments"]
+    h.set_time_slabs(slabs)
+    assert h.work_list_info()["segments"] >= segs0
+    for cost, sigma in (("image_variance", 0), ("gradient_magnitude", 1)):
+        ref = orc.objective(ev, motion, model, size, cost=cost, sigma=sigma)
+        desc = E.make_descriptor(cost, model, sigma=float(sigma))
+        res, grad = h.evaluate(desc, motion)
+        assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+        assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+        assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
+    with pytest.raises(E._lib.CmaxError):  # voxel motions need time BINS
+        h.evaluate(E.make_descriptor("image_variance", "dense-flow-voxel", time_bin=slabs), np.zeros((slabs, 2) + size, np.float32))
+    assert h.suggest_time_slabs(150.0) == 4 and h.suggest_time_slabs(30.0) == 2 and h.suggest_time_slabs(10.0) == 1
+    h.set_time_slabs(0)
+    assert h.work_list_info()["segments"] == segs0
+    res0, grad0 = h.evaluate(desc, motion)
+    assert abs(res0[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())
+
+
 def test_repeated_evaluations_are_consistent():
     """The handle double-buffers its vote images (K2 of evaluation e zeroes the images of e+1): many
     evaluations with changing costs / motions must keep giving the single-shot answer."""

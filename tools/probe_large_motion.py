@@ -16,8 +16,10 @@ H, W, n = 260, 346, 1_000_000
 ev = torch.from_numpy(E.utils.generate_events(n, H, W, 0.0, 0.05, seed=46)).cuda()
 for theta in ((12.3, -7.7), (30.0, -20.0), (50.0, -40.0), (80.0, -60.0), (150.0, -100.0)):
     row = []
-    for tb in (0, 8):
+    for tb, slabs in ((0, 0), (8, 0), (0, 2), (0, 4), (0, 8)):
         h = E.CMaxHandle((H, W)).set_events(ev, time_bin=tb)
+        if slabs:
+            h.set_time_slabs(slabs)
         desc = E.make_descriptor("image_variance", "2d-translation")
         m = torch.tensor(theta, dtype=torch.float32, device="cuda")
         call, raw, fin = h.prepare_raw(desc, m)
@@ -38,6 +40,9 @@ for theta in ((12.3, -7.7), (30.0, -20.0), (50.0, -40.0), (80.0, -60.0), (150.0,
         p = h.read_profile()
         h.set_profiling(False)
         k = {q: v[0] / max(v[1], 1) * 1e3 for q, v in p.items() if v[1]}
-        row.append("%6.1f us (K1 %5.1f K3 %5.1f)" % (float(np.median(ts)), k.get("vote", 0), k.get("grad", 0)))
+        res, grad = h.evaluate(desc, m)
+        row.append("%6.1f us (K1 %5.1f K3 %5.1f) segs %4d loss %.9g g0 %.7g" % (float(np.median(ts)), k.get("vote", 0), k.get("grad", 0), h.work_list_info()["segments"], float(res[0]), float(grad[0])))
         h.close()
-    print("theta = (%6.1f, %6.1f) px per batch:  un-binned %s   |   time_bin 8 %s" % (theta[0], theta[1], row[0], row[1]), flush=True)
+    print("theta = (%6.1f, %6.1f) px per batch:" % theta)
+    for name, r in zip(("un-binned ", "time_bin 8", "slabs 2   ", "slabs 4   ", "slabs 8   "), row):
+        print("    %s %s" % (name, r), flush=True)
