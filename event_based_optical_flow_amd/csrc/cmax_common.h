@@ -55,7 +55,10 @@ struct HandleEvalState {
     uint64_t generation;  // bumped whenever the packed events / work list (and with them device pointers) change
     int profiling;
     int deterministic;  // (read only: part of the key of a captured launch sequence)
+    int mu_buf;         // which of K1's two vote-sum buffers the next evaluation adds into (the blurred variance clears the other one)
 };
+// key of a captured launch sequence: everything of the state that decides which buffers / kernels an evaluation uses
+__attribute__((visibility("hidden"))) uint64_t handle_state_key(const HandleEvalState &st, int kind);
 __attribute__((visibility("hidden"))) void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out);
 __attribute__((visibility("hidden"))) void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in);
 // cmax_flow.hip, for the patch plan: fp64 voxel and (when the single-launch tiled chain ran: *wrote_v32) its fp32 copy

@@ -2468,6 +2468,23 @@ void handle_get_eval_state(cmax_handle_t h, HandleEvalState *out) {
     out->generation = h->generation;
     out->profiling = h->profiling ? 1 : 0;
     out->deterministic = h->deterministic ? 1 : 0;
+    out->mu_buf = h->mu_buf;
+}
+
+uint64_t handle_state_key(const HandleEvalState &st, int kind) {
+    uint64_t sb;
+    std::memcpy(&sb, &st.orig_sigma, sizeof(sb));
+    uint64_t k = (uint64_t)kind;
+    k = k * 1000003u + (uint64_t)st.cur_buf;
+    k = k * 1000003u + st.zero_mask[0];
+    k = k * 1000003u + st.zero_mask[1];
+    k = k * 1000003u + (uint64_t)st.orig_valid;
+    k = k * 1000003u + (uint64_t)st.deterministic;
+    k = k * 1000003u + (uint64_t)st.mu_buf;
+    k = k * 1000003u + (uint64_t)(st.orig_cost + 7);
+    k = k * 1000003u + (uint64_t)(st.orig_omit + 7);
+    k = k * 1000003u + sb;
+    return k;
 }
 
 void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in) {
@@ -2479,6 +2496,7 @@ void handle_set_eval_state(cmax_handle_t h, const HandleEvalState *in) {
     h->orig_omit = in->orig_omit;
     h->orig_sigma = in->orig_sigma;
     for (int k = 0; k < 4; ++k) h->last_iwe[k] = in->last_iwe[k];
+    h->mu_buf = in->mu_buf;
 }
 
 }  // namespace cmax

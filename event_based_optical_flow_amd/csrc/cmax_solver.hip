@@ -449,20 +449,7 @@ int enqueue_hvp(cmax_patch_plan_s *p, hipStream_t s) {
     return 0;
 }
 
-uint64_t state_key(const HandleEvalState &st, int kind) {
-    uint64_t sb;
-    std::memcpy(&sb, &st.orig_sigma, sizeof(sb));
-    uint64_t k = (uint64_t)kind;
-    k = k * 1000003u + (uint64_t)st.cur_buf;
-    k = k * 1000003u + st.zero_mask[0];
-    k = k * 1000003u + st.zero_mask[1];
-    k = k * 1000003u + (uint64_t)st.orig_valid;
-    k = k * 1000003u + (uint64_t)st.deterministic;
-    k = k * 1000003u + (uint64_t)(st.orig_cost + 7);
-    k = k * 1000003u + (uint64_t)(st.orig_omit + 7);
-    k = k * 1000003u + sb;
-    return k;
-}
+uint64_t state_key(const HandleEvalState &st, int kind) { return handle_state_key(st, kind); }
 
 void drop_graphs(cmax_patch_plan_s *p) {
     for (auto &g : p->graphs) (void)hipGraphExecDestroy(g.exec);
