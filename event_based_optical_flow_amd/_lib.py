@@ -110,6 +110,8 @@ SIGNATURES = {
     "cmax_set_events": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_dbl, c_dbl, c_int, c_vp]),
     "cmax_set_time_bins": (c_int, [c_vp, c_int, c_vp]),
     "cmax_set_time_slabs": (c_int, [c_vp, c_int, c_vp]),
+    "cmax_set_keep_outside": (c_int, [c_vp, c_int]),
+    "cmax_batch_outside": (c_int, [c_vp, ctypes.POINTER(ctypes.c_int64)]),
     "cmax_iwe": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_int, c_dbl, c_vp, c_vp]),
     "cmax_objective": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),
     "cmax_objective_host": (c_int, [c_vp, ctypes.POINTER(CmaxObjective), c_vp, c_vp, c_vp, c_vp]),

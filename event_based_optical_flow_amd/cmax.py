@@ -101,6 +101,12 @@ class CMaxHandle:
     # ------------------------------------------------------------------------------------------
     finds_time_extremes = True  # set_events(ev, None, None, ...) reduces t_min / t_max on the device
 
+    def set_keep_outside(self, on: bool = True):
+        """Keep finite events whose source pixel lies OFF the sensor (cmax_set_keep_outside; next set_events on): the reference's
+        2-DoF warp lets them vote wherever they warp into the padded image (src/warp.py:506-515).  2-DoF objectives only."""
+        check(self._lib.cmax_set_keep_outside(self._h, int(bool(on))))
+        return self
+
     def set_events(self, events, tmin: Optional[float] = None, tmax: Optional[float] = None, time_bin: int = 0,
                    on_dropped: str = "warn"):
         """Pack + sort one [n,4] batch (numpy or tensor, fp32/fp64).  (tmin, tmax): global batch
@@ -124,18 +130,20 @@ class CMaxHandle:
         if dropped and on_dropped == "raise":
             raise ValueError(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events whose source pixel is outside the "
                              f"{self.image_size[0]} x {self.image_size[1]} sensor (or NaN); use the leaf operators (Warp + "
-                             "EventImageConverter) for such batches, or crop / pad the sensor")
+                             "EventImageConverter) for such batches, set_keep_outside() for a 2-DoF objective, or crop / pad the sensor")
         if dropped:
             logger.warning(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events: source pixel outside the "
                            f"{self.image_size[0]} x {self.image_size[1]} sensor (or NaN); the fused path cannot keep them")
         return self
 
     def batch_info(self) -> Dict[str, int]:
-        """{"packed", "dropped", "fractional", "owned_groups"} of the last set_events (cmax_batch_info)."""
+        """{"packed", "dropped", "fractional", "owned_groups", "outside"} of the last set_events (cmax_batch_info, cmax_batch_outside)."""
         n, d = ctypes.c_int64(0), ctypes.c_int64(0)
         f, o = ctypes.c_int(0), ctypes.c_int(0)
         check(self._lib.cmax_batch_info(self._h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(f), ctypes.byref(o)))
-        return {"packed": n.value, "dropped": d.value, "fractional": bool(f.value), "owned_groups": bool(o.value)}
+        out = ctypes.c_int64(0)
+        check(self._lib.cmax_batch_outside(self._h, ctypes.byref(out)))
+        return {"packed": n.value, "dropped": d.value, "fractional": bool(f.value), "owned_groups": bool(o.value), "outside": out.value}
 
     def work_list_info(self) -> Dict[str, int]:
         """{"segments", "segment_events", "small_accumulators"} of the work list the last set_events / set_time_bins cut

@@ -161,6 +161,8 @@ struct cmax_handle_s {
     int device = 0;
     int64_t n = 0, cap = 0;
     int64_t n_dropped = 0;  // events of the last batch whose source pixel was off the sensor (or NaN): not packed
+    bool keep_outside = false;  // cmax_set_keep_outside: finite events off the sensor are packed (nearest sensor pixel + residual)
+    int64_t n_outside = 0;      // ... how many of the last batch (2-DoF objectives only: a flow has no value there)
     bool has_frac = false;
     int n_time_bin = 0;
     bool slab_major = false;  // the (tile, bin) groups are ordered (tile row, time slab, tile column): cmax_set_time_slabs (large motions)
@@ -2205,6 +2207,7 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         h->n = rb->n_in - rb->flags[1];
         if (h->generation_counted != h->generation) {  // a new batch (re-binning keeps the count of cmax_set_events)
             h->n_dropped = rb->flags[1];
+            h->n_outside = rb->flags[2];
             h->generation_counted = h->generation;
         }
         int64_t active = 0;  // source pixels that hold events (un-binned order)
@@ -2629,6 +2632,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     h->orig_valid = false;
     h->n = 0;
     h->n_dropped = 0;
+    h->n_outside = 0;
     ++h->generation;
     h->generation_counted = ~(uint64_t)0;
     if (n > h->cap) {
@@ -2668,8 +2672,9 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     }
     // pack + order (tile-major; by pixel or by time bin inside a tile) + work list; one host synchronisation
     const int keyed = have_tminmax ? 0 : 1;
-    if (dtype == CMAX_F32) return sort_events(h, RawSource<float>{(const float *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, 0, s);
-    return sort_events(h, RawSource<double>{(const double *)events, h->d_tmm, h->H, h->W, keyed}, n, keyed != 0, 0, s);
+    const int keep = h->keep_outside ? 1 : 0;
+    if (dtype == CMAX_F32) return sort_events(h, RawSource<float>{(const float *)events, h->d_tmm, h->H, h->W, keyed, keep}, n, keyed != 0, 0, s);
+    return sort_events(h, RawSource<double>{(const double *)events, h->d_tmm, h->H, h->W, keyed, keep}, n, keyed != 0, 0, s);
 }
 
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
@@ -2705,6 +2710,7 @@ int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mod
     CMAX_REQUIRE(model <= CMAX_MODEL_VOXEL, "iwe: model");
     CMAX_REQUIRE(model != CMAX_MODEL_VOXEL || (T > 0 && T == h->n_time_bin), "iwe: voxel T must match the handle's time bins");
     CMAX_REQUIRE(model != CMAX_MODEL_VOXEL || !h->slab_major, "iwe: a voxel motion needs time BINS (cmax_set_time_bins), this handle is in slab order");
+    CMAX_REQUIRE(model <= CMAX_MODEL_2DOF || h->n_outside == 0, "iwe: the batch holds events off the sensor (cmax_set_keep_outside): 2-DoF / un-warped only");
     hipStream_t s = (hipStream_t)stream;
     float *raw = sigma > 0 ? h->G : iwe_out;  // G is scratch outside cmax_objective
     int rc = vote_image(h, model, motion, T, ref_mode, ref_frac, normalize_t, raw, false, -1, s);
@@ -2738,6 +2744,8 @@ static int check_objective_args(cmax_handle_t h, const cmax_objective_t *d, cons
                  "objective: motion_dtype must be CMAX_F32, or CMAX_F64 for the 2-DoF model");
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || (d->T > 0 && d->T == h->n_time_bin), "objective: voxel T must match the handle's time bins");
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || !h->slab_major, "objective: a voxel motion needs time BINS (cmax_set_time_bins), this handle is in slab order");
+    CMAX_REQUIRE(d->model == CMAX_MODEL_2DOF || h->n_outside == 0,
+                 "objective: the batch holds events off the sensor (cmax_set_keep_outside): only the 2-DoF model is defined for them -- a flow has no value there");
     CMAX_REQUIRE(!d->omit_boundary || (h->Hp > 2 && h->Wp > 2), "objective: image too small for omit_boundary");
     CMAX_REQUIRE((int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W * 4 < ((int64_t)1 << 32),
                  "objective: the motion field must be smaller than 4 GiB (32-bit byte offsets in the event kernels)");
@@ -3996,6 +4004,7 @@ int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h,
         h->search_cap = n_patch;
     }
     CMAX_REQUIRE(!h->slab_major, "patch_search: the handle is in slab order (cmax_set_time_slabs); the search walks tile-major groups");
+    CMAX_REQUIRE(h->n_outside == 0, "patch_search: the batch holds events off the sensor (cmax_set_keep_outside)");
     SearchArgs a;
     a.evp = h->evp;
     a.rx = h->rx;
@@ -4023,6 +4032,18 @@ int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int 
     if (n_dropped) *n_dropped = h->n_dropped;
     if (has_fractional) *has_fractional = h->has_frac ? 1 : 0;
     if (owned_groups) *owned_groups = h->owned ? 1 : 0;
+    return 0;
+}
+
+int cmax_set_keep_outside(cmax_handle_t h, int on) {
+    CMAX_REQUIRE(h != nullptr, "set_keep_outside");
+    h->keep_outside = on != 0;  // takes effect with the next cmax_set_events
+    return 0;
+}
+
+int cmax_batch_outside(cmax_handle_t h, int64_t *n_outside) {
+    CMAX_REQUIRE(h != nullptr && n_outside != nullptr, "batch_outside");
+    *n_outside = h->n_outside;
     return 0;
 }
 

@@ -78,6 +78,7 @@ struct SortItem {
     float rx, ry;   // fractional parts of the source coordinates
     double tn;      // time normalised to the batch
     bool frac;
+    bool outside;   // kept although off the sensor (RawSource::keep_outside): (ix, iy) is the NEAREST sensor pixel, (rx, ry) the rest
 };
 
 // raw [n,4] = (x row, y column, t, p) in T (fp32 / fp64)
@@ -87,6 +88,7 @@ struct RawSource {
     const double *tmm;  // (t_min, t_max) of the batch, on the device
     int H, W;
     int keyed;          // tmm still holds the keys of the reduction fused into S1 (see sort_f64_key)
+    int keep_outside;   // cmax_set_keep_outside: finite events off the sensor are packed at the nearest sensor pixel + a residual
     __device__ __forceinline__ bool reduces_time() const { return keyed != 0; }
     __device__ __forceinline__ double time(int64_t i) const { return (double)ev[4 * i + 2]; }
     __device__ __forceinline__ SortItem pixel(int64_t i) const {  // S1: the pixel only
@@ -98,10 +100,16 @@ struct RawSource {
         it.ix = -1;
         it.iy = 0;
         it.frac = false;
+        it.outside = false;
         if (fx >= (T)0 && fx < (T)H && fy >= (T)0 && fy < (T)W) {  // NaN fails every comparison -> dropped
             it.ix = (int)fx;
             it.iy = (int)fy;
             it.frac = x != fx || y != fy;
+        } else if (keep_outside && fx > (T)-1048576 && fx < (T)1048576 && fy > (T)-1048576 && fy < (T)1048576) {  // (finite, sane)
+            it.ix = fx < (T)0 ? 0 : (fx >= (T)H ? H - 1 : (int)fx);
+            it.iy = fy < (T)0 ? 0 : (fy >= (T)W ? W - 1 : (int)fy);
+            it.frac = true;
+            it.outside = true;
         }
         return it;
     }
@@ -109,8 +117,8 @@ struct RawSource {
         const T x = ev[4 * i + 0], y = ev[4 * i + 1];
         SortItem it = classify(x, y);
         if (it.ix >= 0) {
-            it.rx = (float)(x - floor_t<T>(x));
-            it.ry = (float)(y - floor_t<T>(y));
+            it.rx = (float)(x - (T)it.ix);  // (on the sensor: ix = floor(x))
+            it.ry = (float)(y - (T)it.iy);
             double tmin = tmm[0], tmax = tmm[1];
             if (keyed) {
                 const unsigned long long *k = reinterpret_cast<const unsigned long long *>(tmm);
@@ -138,6 +146,7 @@ struct PackedSource {
         it.ix = (int)(pk & 0xFFFu);
         it.iy = (int)((pk >> 12) & 0xFFFu);
         it.frac = false;
+        it.outside = false;
         return it;
     }
     __device__ __forceinline__ SortItem full(int64_t i) const {
@@ -166,7 +175,8 @@ __global__ void __launch_bounds__(256) k_sort_clear(int *__restrict__ tile_count
     if (tmm_keys && i < 2) tmm_keys[i] = 0ull;  // "empty" for both atomicMax reductions
 }
 
-// S1.  tile_count[ntiles] += events per tile; flags[0] = any fractional source coordinate, flags[1] += dropped events;
+// S1.  tile_count[ntiles] += events per tile; flags[0] = any fractional source coordinate, flags[1] += dropped events,
+// flags[2] += events kept off the sensor;
 // tmm_keys (RawSource with keyed extremes): batch time extremes, two atomics per workgroup.
 template <typename SRC>
 __global__ void __launch_bounds__(kSortThreads)
@@ -180,7 +190,7 @@ k_bucket_hist(SRC src, int64_t n, int ntc, int ntiles, int *__restrict__ tile_co
         __syncthreads();
     }
     const int64_t base = (int64_t)blockIdx.x * kSortChunk;
-    int dropped = 0;
+    int dropped = 0, outside = 0;
     bool frac = false;
     double lo = INFINITY, hi = -INFINITY;
 #pragma unroll
@@ -198,6 +208,7 @@ k_bucket_hist(SRC src, int64_t n, int ntc, int ntiles, int *__restrict__ tile_co
             continue;
         }
         frac = frac || it.frac;
+        outside += it.outside ? 1 : 0;
         const int tile = (it.ix >> 4) * ntc + (it.iy >> 4);
         if (lds) atomicAdd(&s_hist[tile], 1);
         else atomicAdd(&tile_count[tile], 1);
@@ -206,6 +217,11 @@ k_bucket_hist(SRC src, int64_t n, int ntc, int ntiles, int *__restrict__ tile_co
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0 && dropped) atomicAdd(&flags[1], dropped);
+    if (__any(outside != 0)) {  // (rare: batches from a sensor have none)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) outside += __shfl_xor(outside, o, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&flags[2], outside);
+    }
     if (src.reduces_time()) {
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {

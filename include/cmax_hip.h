@@ -409,12 +409,23 @@ int cmax_sizeof_objective(void);
 int cmax_copy_iwe(cmax_handle_t h, int k, float *iwe_out, cmax_stream_t stream);
 
 /* What cmax_set_events made of the last batch: events packed; events DROPPED because their source pixel lies
- * outside the sensor or is NaN (the fused path indexes the flow field and the source tiles with it, so such
- * events cannot be kept -- the leaf operators cmax_warp_events + cmax_vote have no such filter and follow the
- * reference, which lets a 2-DoF event from outside the sensor vote if it warps into the padded image); whether
+ * outside the sensor or is NaN (the fused path indexes the flow field and the source tiles with it; for 2-DoF
+ * objectives cmax_set_keep_outside below keeps them, as the reference does -- the leaf operators cmax_warp_events +
+ * cmax_vote have no such filter either way); whether
  * any source coordinate is fractional; whether the work list gives every group to one segment (owned groups:
  * single-reference dense / voxel gradients are then stored, not added).  Any pointer may be NULL.            */
 int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int *has_fractional, int *owned_groups);
+/* Events OFF THE SENSOR (round 4).  The reference's 2-DoF warp has no bounds test on the source (src/warp.py:506-515): an event from
+ * outside the sensor votes wherever it warps into the padded image.  With cmax_set_keep_outside(h, 1) the next cmax_set_events packs
+ * such events (finite coordinates) instead of dropping them: at the NEAREST sensor pixel, the rest of the way in the fp32 residuals
+ * that fractional source coordinates use -- the event kernels then see x = ix + rx exactly as for any fractional source (a residual of
+ * r px carries ulp(r) / 2 of rounding: 4e-6 px at 100 px).  cmax_batch_outside reports how many the last batch held; they count as
+ * packed, not as dropped.  Only the 2-DoF model (and the un-warped image) is defined for them: a dense / voxel objective, cmax_iwe of
+ * those models and cmax_patch_search refuse a batch that holds any (CMAX_EINVAL) -- the reference indexes its flow with the source
+ * pixel there (negative indices wrap around in torch; nothing a caller can mean).  Default: off (events off the sensor are dropped
+ * and counted, as in rounds 1-3).                                                                                               */
+int cmax_set_keep_outside(cmax_handle_t h, int on);
+int cmax_batch_outside(cmax_handle_t h, int64_t *n_outside);
 /* The work list cmax_set_events / cmax_set_time_bins cut for the event kernels (one workgroup per segment): number of
  * segments; segment_events = the most events a segment holds (2040, or 4088 for BIG segments: batches of >= 8M events, and
  * smaller ones whose group sizes ask for it -- DESIGN.md section 2); small_accumulators = 1 when a binned list was cut at

@@ -805,6 +805,29 @@ def gen_costs_batched():
     np.savez_compressed(os.path.join(HERE, "costs_batched.npz"), **out)
 
 
+def gen_outside_sensor():
+    """2-DoF objective on a batch a third of which starts up to 25 px OFF the sensor: the reference's warp has no bounds test on the
+    source (warp.py:506-515), the vote masks what lands outside the padded image (event_image_converter.py:340-380)."""
+    rng = np.random.default_rng(SEED + 17)
+    H, W = 48, 64
+    ev = make_events(8000, H, W, rng, fractional=True)
+    off = rng.random(ev.shape[0]) < 0.33
+    ev[off, 0] = rng.uniform(-25.0, H + 25.0, int(off.sum()))
+    ev[off, 1] = rng.uniform(-25.0, W + 25.0, int(off.sum()))
+    ev[::7, 0] = np.floor(ev[::7, 0])
+    theta = np.array([17.0, -21.0])
+    out = dict(events=ev, theta=theta, image_size=np.array([H, W]), shims=np.array(ref_import.SHIMS))
+    for pad in (0, 6):
+        for cost_name, sigma in (("image_variance", 0), ("gradient_magnitude", 1), ("normalized_image_variance", 1)):
+            fs = _fake_solver(H, W, cost_name, sigma, pad=pad)
+            loss, gs, iwes = _ref_objective(fs, ev, theta, "2d-translation", None)
+            tag = f"pad{pad}__{cost_name}__s{sigma}"
+            out[tag + "__loss"] = np.array(loss)
+            out[tag + "__grad"] = gs[0].numpy()
+            out[tag + "__iwe"] = iwes["iwe"]
+    np.savez_compressed(os.path.join(HERE, "outside_sensor.npz"), **out)
+
+
 def gen_core():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
@@ -820,10 +843,10 @@ def gen_core():
 
 if __name__ == "__main__":
     # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search] [solver_optimize]
-    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized]   (no argument = everything)
+    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized] [outside_sensor]   (no argument = everything)
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
                                                                     "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv", "costs_batched",
-                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized"]
+                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized", "outside_sensor"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -850,3 +873,5 @@ if __name__ == "__main__":
         gen_cfg2_fp32_reference()
     if "warp_voxel_optimized" in which:
         gen_warp_voxel_optimized()
+    if "outside_sensor" in which:
+        gen_outside_sensor()

@@ -282,6 +282,55 @@ def test_out_of_sensor_sources_are_dropped_not_crashing():
     assert abs(float(iwe.sum()) - keep.sum()) < 1e-3
 
 
+@pytest.mark.parametrize("pad", [0, 6])
+@pytest.mark.parametrize("cost,sigma", [("image_variance", 0), ("gradient_magnitude", 1), ("normalized_image_variance", 0)])
+def test_events_off_the_sensor_vote_like_the_reference(pad, cost, sigma):
+    """cmax_set_keep_outside: the reference's 2-DoF warp has no bounds test on the source (src/warp.py:506-515) -- an event from outside
+    the sensor votes wherever it warps into the padded image.  A third of this batch starts up to 25 px outside; theta brings part of
+    it in.  Against the oracle (which follows the reference): IWE, loss, gradient; NaN / absurd coordinates are still dropped; dense
+    objectives refuse such a batch."""
+    size, n = (64, 80), 60_000
+    rng = np.random.default_rng(91)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=90)
+    out = rng.random(n) < 0.33
+    ev[out, 0] = rng.uniform(-25.0, size[0] + 25.0, int(out.sum()))
+    ev[out, 1] = rng.uniform(-25.0, size[1] + 25.0, int(out.sum()))
+    ev[::7, 0] = np.floor(ev[::7, 0])  # integer and fractional coordinates mixed
+    theta = np.array([17.0, -21.0])
+    ref = orc.objective(ev, theta, "2d-translation", size, cost=cost, sigma=sigma, outer_padding=pad)
+    bad = ev.copy()
+    bad = np.concatenate([bad, np.array([[np.nan, 3.0, 0.01, 1.0], [1e12, 3.0, 0.01, 1.0]])])  # dropped either way
+    h = E.CMaxHandle(size, outer_padding=pad).set_keep_outside(True).set_events(bad, on_dropped="ignore")
+    info = h.batch_info()
+    off = (np.floor(ev[:, 0]) < 0) | (np.floor(ev[:, 0]) >= size[0]) | (np.floor(ev[:, 1]) < 0) | (np.floor(ev[:, 1]) >= size[1])
+    assert info["packed"] == n and info["dropped"] == 2 and info["outside"] == int(off.sum()) and info["fractional"]
+    desc = E.make_descriptor(cost, "2d-translation", sigma=float(sigma))
+    res, grad = h.evaluate(desc, theta)
+    assert rel_max(h.last_iwe(0).cpu().numpy(), ref["iwes"]["iwe"]) <= TOL
+    assert abs(res[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_max(grad.cpu().numpy(), ref["grad"]) <= TOL
+    with pytest.raises(E._lib.CmaxError):
+        h.evaluate(E.make_descriptor(cost, "dense-flow", sigma=float(sigma)), np.zeros((2,) + size, np.float32))
+    # default handles drop them, as before
+    h2 = E.CMaxHandle(size, outer_padding=pad).set_events(ev, on_dropped="ignore")
+    assert h2.batch_info()["dropped"] == int(off.sum()) and h2.batch_info()["outside"] == 0
+
+
+@pytest.mark.parametrize("pad", [0, 6])
+@pytest.mark.parametrize("cost,sigma", [("image_variance", 0), ("gradient_magnitude", 1), ("normalized_image_variance", 1)])
+def test_events_off_the_sensor_golden(golden, pad, cost, sigma):
+    """... and against the reference itself (tests/golden/outside_sensor.npz)."""
+    g = golden("outside_sensor")
+    size = tuple(int(v) for v in g["image_size"])
+    tag = f"pad{pad}__{cost}__s{sigma}"
+    h = E.CMaxHandle(size, outer_padding=pad).set_keep_outside(True).set_events(g["events"])
+    assert h.batch_info()["dropped"] == 0 and h.batch_info()["outside"] > 1000
+    res, grad = h.evaluate(E.make_descriptor(cost, "2d-translation", sigma=float(sigma)), g["theta"])
+    assert rel_max(h.last_iwe(0).cpu().numpy(), g[tag + "__iwe"]) <= TOL
+    assert abs(res[0].item() - float(g[tag + "__loss"])) <= TOL * abs(float(g[tag + "__loss"]))
+    assert rel_max(grad.cpu().numpy(), g[tag + "__grad"]) <= TOL
+
+
 def test_everything_warps_out_of_the_image():
     ev = E.utils.generate_events(2000, 32, 40, seed=2)
     h = E.CMaxHandle((32, 40)).set_events(ev)

@@ -353,3 +353,19 @@ def test_warp_voxel_optimized(golden, n_bin, direction):
     size = tuple(int(v) for v in g["image_size"])
     w, _ = orc.warp_event(g["events"], g["flow"], "dense-flow-voxel-optimized", direction, size, flow_propagate_bin=n_bin)
     np.testing.assert_allclose(w, g[f"T{n_bin}_{direction}"], rtol=0, atol=1e-12)
+
+
+OUTSIDE_CASES = [(pad, c, s) for pad in (0, 6) for c, s in (("image_variance", 0), ("gradient_magnitude", 1), ("normalized_image_variance", 1))]
+
+
+@pytest.mark.parametrize("pad,cost,sigma", OUTSIDE_CASES)
+def test_events_off_the_sensor_2dof(golden, pad, cost, sigma):
+    """The reference's 2-DoF warp takes events from OUTSIDE the sensor (no bounds test on the source, src/warp.py:506-515); the vote
+    masks what lands outside the padded image.  Fixture: the reference run on a batch a third of which starts up to 25 px outside."""
+    g = golden("outside_sensor")
+    size = tuple(int(v) for v in g["image_size"])
+    tag = f"pad{pad}__{cost}__s{sigma}"
+    r = orc.objective(g["events"], g["theta"], "2d-translation", size, cost=cost, sigma=sigma, outer_padding=pad)
+    assert abs(r["loss"] - float(g[tag + "__loss"])) <= 1e-11 * abs(float(g[tag + "__loss"]))
+    assert np.abs(r["grad"] - g[tag + "__grad"]).max() <= 1e-10 * np.abs(g[tag + "__grad"]).max()
+    assert np.abs(r["iwes"]["iwe"] - g[tag + "__iwe"]).max() <= 1e-11
