@@ -668,6 +668,18 @@ __device__ __forceinline__ int cvt_rpi(float x) {
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// 24-bit multiplies with a UNIFORM second factor, spelled out: the compiler takes v_mul_lo_u32 / v_mul_hi_u32 whenever it cannot
+// prove both factors below 2^24 (a run-time window stride: K1's vote index, one per event).  `b` must be wave-uniform.
+__device__ __forceinline__ unsigned mul24_u(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b), "v"(a));
+    return r;
+}
+__device__ __forceinline__ unsigned mad24_u(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 typedef unsigned short ushort2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {  // v_pk_min_u16: both 16-bit halves at once
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(ushort2_v, a), __builtin_bit_cast(ushort2_v, b)));
