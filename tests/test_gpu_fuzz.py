@@ -206,6 +206,49 @@ def test_one_handle_many_batches():
             assert abs(loss.item() - ref["loss"]) <= 3e-4 * abs(ref["loss"]), (it, "rebinned", loss.item(), ref["loss"])
 
 
+# ---- time slabs and events off the sensor on random batches (round 4) ----------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_random_time_slabs_and_outside_events_against_oracle(seed):
+    """cmax_set_time_slabs is only an ORDER of the batch (2-DoF and dense objectives, any cost, exact product included); with
+    cmax_set_keep_outside a 2-DoF batch keeps its events from off the sensor.  Random sizes, slab counts, motions up to 120 px."""
+    rng = np.random.default_rng(4100 + seed)
+    H, W = int(rng.integers(40, 130)), int(rng.integers(40, 170))
+    pad = int(rng.choice([0, 3]))
+    n = int(rng.choice([500, 20000, 150000]))
+    ev = E.utils.generate_events(n, H, W, 0.0, 0.05, seed=seed)
+    outside = seed % 2 == 1
+    if outside:
+        sel = rng.random(n) < 0.25
+        ev[sel, 0] = rng.uniform(-30.0, H + 30.0, int(sel.sum()))
+        ev[sel, 1] = rng.uniform(-30.0, W + 30.0, int(sel.sum()))
+    h = E.CMaxHandle((H, W), pad)
+    if outside:
+        h.set_keep_outside(True)
+    h.set_events(ev, on_dropped="ignore")
+    for slabs in (0, int(rng.choice([2, 3, 5, 8]))):
+        h.set_time_slabs(slabs)
+        for model in (("2d-translation",) if outside else ("2d-translation", "dense-flow")):
+            mag = float(rng.choice([4.0, 40.0, 120.0]))
+            motion = rng.uniform(-mag, mag, 2) if model == "2d-translation" else E.utils.generate_smooth_flow((H, W), mag, grid=3, seed=seed + 7)
+            cost, sigma = str(rng.choice(COSTS)), int(rng.integers(0, 2))
+            ref = orc.objective(ev, motion, model, (H, W), cost=cost, sigma=sigma, outer_padding=pad)
+            desc = E.make_descriptor(cost, model, sigma=float(sigma))
+            res, grad = h.evaluate(desc, motion)
+            info = (seed, H, W, pad, n, slabs, model, cost, sigma, mag, outside)
+            assert abs(res[0].item() - ref["loss"]) <= 3e-4 * abs(ref["loss"]), (info, res[0].item(), ref["loss"])
+            gmax = np.abs(ref["grad"]).max()
+            err = np.abs(grad.double().cpu().numpy() - ref["grad"])
+            assert (err > 3e-4 * gmax).sum() <= 8 and err.max() <= 5e-2 * gmax, (info, err.max(), gmax)
+    # the exact Hessian-vector product does not depend on the order either
+    desc = E.make_descriptor("image_variance", "2d-translation", sigma=1.0)
+    theta, v = np.array([11.0, -6.0]), np.array([0.3, 0.8])
+    h.set_time_slabs(0)
+    hv0 = h.hvp(desc, theta, v).double().cpu().numpy()
+    h.set_time_slabs(4)
+    hv4 = h.hvp(desc, theta, v).double().cpu().numpy()
+    assert np.abs(hv4 - hv0).max() <= 1e-5 * np.abs(hv0).max(), (seed, hv0, hv4)
+
+
 # ---- per-patch search on random boxes ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", range(8))
 def test_random_patch_search_against_oracle(seed):
