@@ -3093,10 +3093,23 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     ra.shifts = h->d_shifts;
     ra.n_events = h->n;
     if (stats_inside) {
-        // two sweeps of 4 pixels per thread (cfg5, K3 with 1 / 2 / 4 / 8 sweeps: 18.8 / 17.9 / 18.3 / 18.3 us; tuning: CMAX_STAT_SWEEPS)
-        static const int sweeps = getenv("CMAX_STAT_SWEEPS") ? std::max(1, atoi(getenv("CMAX_STAT_SWEEPS"))) : 2;
-        const int64_t per_block = 4 * (int64_t)grad_threads(h, d->model) * sweeps;
-        ra.stat_blocks = (int)std::min<int64_t>(8 * div_up(div_up(npix, per_block), 8), 8 * (kStatBlocksMax / 8));
+        // Sweeps of 4 pixels per thread and statistics workgroup: two (round 3, standard segments: K3 of cfg5 with 1 / 2 / 4 / 8 sweeps 18.8 /
+        // 17.9 / 18.3 / 18.3 us) -- unless the gathering workgroups fit the chip in ONE round and the statistics workgroups are what
+        // spills into a second: then four, if that makes the launch fit (round 4, mid segments: cfg5's shard is 900 gathering workgroups;
+        // with 232 statistics workgroups 1132 > 1024 resident, with 120 it fits -- K3 16.1 -> 14.8 us, the evaluation 28.8 -> 27.4 us;
+        // 3 / 4 / 6 / 8 / 16 sweeps: 28.8 / 27.4 / 27.6 / 27.8 / 31.3 us, profiles/r04_ablation.txt 15).  CMAX_STAT_SWEEPS overrides.
+        static const int sweeps_env = getenv("CMAX_STAT_SWEEPS") ? std::max(1, atoi(getenv("CMAX_STAT_SWEEPS"))) : 0;
+        const int gthreads = grad_threads(h, d->model);
+        auto blocks_for = [&](int sweeps) {
+            const int64_t per_block = 4 * (int64_t)gthreads * sweeps;
+            return (int)std::min<int64_t>(8 * div_up(div_up(npix, per_block), 8), 8 * (kStatBlocksMax / 8));
+        };
+        int sweeps = sweeps_env ? sweeps_env : 2;
+        if (!sweeps_env) {
+            const int resident = 256 * (2048 / gthreads), gather = 8 * div_up(h->nseg, 8) * d->n_ref;  // workgroups the chip holds at once
+            if (gather <= resident && gather + blocks_for(2) * d->n_ref > resident && gather + blocks_for(4) * d->n_ref <= resident) sweeps = 4;
+        }
+        ra.stat_blocks = blocks_for(sweeps);
         ra.ticket = h->d_ticket;
         ra.musum[0] = h->d_musum + (int64_t)h->mu_buf * 4 * kMuStride;
         ra.musum_next = h->d_musum + (int64_t)(h->mu_buf ^ 1) * 4 * kMuStride;
