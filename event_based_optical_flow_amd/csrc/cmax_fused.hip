@@ -120,6 +120,11 @@ struct RefArgs {
     long long *g64;            // K3: 2-DoF per-segment partial sums [n_ref][nseg][2] / flow-gradient accumulators, fixed point
     double *det_inv_scale;     // K3: [4] 1 / scale used by reference time k (2-DoF) or by all of them ([0], flow gradient)
     long long n_events;        // K3: events behind one accumulator at most (fixed-point headroom)
+    // K1: the flow-gradient buffer the K3 of this evaluation ADDS into (work lists that are not group-aligned), cleared slice by slice
+    // behind the event loads -- so that the statistics can run inside the K3 launch there too (kFoldStatsInside) instead of in a
+    // launch of their own whose second job this was
+    float4 *grad_zero;
+    int64_t n_grad_zero4;
 };
 
 // the image-space kernels of an evaluation cover all reference times in one launch as well (blockIdx.y)
@@ -232,6 +237,9 @@ struct cmax_handle_s {
     unsigned long long host_seq = 0;  // run counter of the finishing kernel that writes into hp_out (polled by cmax_objective_host)
     int *d_ticket = nullptr;    // arrival counters of the statistics workgroups inside K3 (kFoldStatsInside): zero between launches
     double *d_musum = nullptr;  // [2 buffers][4 reference times][kMuStride] K1's sums for the blurred variance (RefArgs::musum)
+    float4 *vote_clear4 = nullptr;      // objective_eval -> vote_images: gradient buffer K1 is to clear (RefArgs::grad_zero), consumed by the launch
+    int64_t vote_nclear4 = 0;
+    const void *grad_cleared_by_vote = nullptr;  // ... and which buffer the K1 launch of the current evaluation did clear
     int mu_buf = 0;             // buffer the next evaluation adds into (the other one is being cleared / is clear)
     bool mu_valid = false;      // the K1 launch of the current cmax_objective call filled d_musum[mu_buf]
     // orig-IWE cache key
@@ -1935,9 +1943,13 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
         if constexpr (MODEL == CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldDeferred); } \
     } else if (fold == kFoldStatsInside) {                                                   \
         if constexpr (MODEL == CMAX_MODEL_VOXEL && NS::kThr == 512 && NS::kSlots <= 3072) {   \
-            if (small) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwnedSmall); } \
+            if (!owned) { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStatsInside); }                    \
+            else if (small) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwnedSmall); } \
             else { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); }            \
-        } else if constexpr (MODEL != CMAX_MODEL_2DOF) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); } \
+        } else if constexpr (MODEL != CMAX_MODEL_2DOF) {                                     \
+            if (owned) { CMAX_LAUNCH_GRAD_L(NS, FRAC, kFoldStatsInside, kGradOwned); }       \
+            else { CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStatsInside); }                           \
+        }                                                                                    \
     } else if (fold == kFoldStats) {                                                         \
         CMAX_LAUNCH_GRAD(NS, FRAC, kFoldStats);                                              \
     } else if (fold == kFoldScale) {                                                         \
@@ -2019,6 +2031,11 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
     RefArgs ra = {};
     ra.k0 = 0;
     ra.raw_zero = raw_lines;  // (the deferred objective resets its sums through ra.stat instead: raw_reset)
+    ra.grad_zero = h->vote_clear4;
+    ra.n_grad_zero4 = h->vote_nclear4;
+    h->grad_cleared_by_vote = h->vote_clear4;
+    h->vote_clear4 = nullptr;
+    h->vote_nclear4 = 0;
     if (publish_windows && h->n > 0) {  // K3 of the same evaluation re-uses the LDS windows (see objective_finish)
         ra.win = h->d_win;
         ra.shifts = h->d_shifts;
@@ -2951,8 +2968,10 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     // order that matches the model (dense: tiles; voxel: (tile, bin) of the same T).
     const bool owned = owned_groups_apply(h, d, grad);
     // plain variance, not normalised, owned groups, K1 of this call summed its votes: the statistics run inside the K3 launch
-    const bool stats_inside = owned && fold_var && !d->normalized && reuse_windows && h->mu_valid;
-    const bool grad_cleared_by_stats = grad && !two_dof && !owned && !det && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
+    const bool cleared_by_vote = grad && reuse_windows && h->grad_cleared_by_vote == grad && !owned;  // K1 of this call cleared the gradient buffer
+    h->grad_cleared_by_vote = nullptr;
+    const bool stats_inside = (owned || cleared_by_vote) && fold_var && !d->normalized && reuse_windows && h->mu_valid && !det;
+    const bool grad_cleared_by_stats = grad && !two_dof && !owned && !cleared_by_vote && !det && h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
     float4 *clear4 = grad_cleared_by_stats ? (float4 *)grad : nullptr;
     const int64_t nclear4 = grad_cleared_by_stats ? gcount / 4 : 0;
     double k0 = 0, k1 = 0;
@@ -3014,7 +3033,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     }
 
     // ---- backward: dL/dIWE (folded into K3 for the plain variance; otherwise a G image per reference time)
-    if (!two_dof && !grad_cleared_by_stats && !owned && !det) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
+    if (!two_dof && !grad_cleared_by_stats && !cleared_by_vote && !owned && !det) CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
     const int fold = deferred ? kFoldDeferred
                               : (stats_inside ? kFoldStatsInside
                                               : (fold_var ? kFoldStats : (((fused_gm || fused_bv) && d->normalized) ? kFoldScale : kFoldNone)));
@@ -3305,8 +3324,16 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     // plain variance (no blur, not normalised) on owned groups: nothing in the gradient needs the finished statistics once the
     // mean comes from the votes, so K2 runs inside the K3 launch (kFoldStatsInside)
     static const bool no_stats_inside = getenv("CMAX_NO_STATS_INSIDE") != nullptr;  // tuning: k_stats as a launch of its own
-    const bool var_from_votes = !dist && !no_stats_inside && owned_groups_apply(h, d, grad) && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) &&
-                                !d->normalized && h->Hp >= 4 && h->Wp >= 4;
+    // ... and on work lists that are not group-aligned (K3 adds its gradient with atomics) once K1 clears the gradient buffer -- the
+    // other job of the separate statistics launch (round 4: 20M events 88.5 -> see profiles/r04_ablation.txt 16)
+    const bool inside_ok = !dist && !no_stats_inside && d->cost == CMAX_COST_VARIANCE && !(d->sigma > 0) && !d->normalized && h->Hp >= 4 && h->Wp >= 4;
+    const bool clear_by_vote = inside_ok && grad && !owned_groups_apply(h, d, grad) && d->model != CMAX_MODEL_2DOF && d->n_ref == 1 && !h->deterministic &&
+                               h->n > 0 && gcount % 4 == 0 && ((uintptr_t)grad & 15u) == 0;
+    if (clear_by_vote) {
+        h->vote_clear4 = (float4 *)grad;
+        h->vote_nclear4 = gcount / 4;
+    }
+    const bool var_from_votes = inside_ok && (owned_groups_apply(h, d, grad) || clear_by_vote);
     // 2-DoF objectives: K1 clears the raw sums its K3 adds into -- through its statistics slot when the objective keeps none
     // (deferred), through RefArgs::raw_zero otherwise
     double *raw = two_dof_lines(h, d, grad) ? (raw_out ? raw_out : h->d_raw) : nullptr;
