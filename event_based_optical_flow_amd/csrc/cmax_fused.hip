@@ -50,6 +50,7 @@
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
 //   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
+//   CMAX_SEG_CAP=n        free-cut work lists: events per segment (<= the layout's cap; profiles/r04_ablation.txt 18)
 //   CMAX_NO_STATS_INSIDE=1   plain variance on owned groups: k_stats as a launch of its own instead of inside K3's
 //   CMAX_STAT_SWEEPS=n       statistics inside K3's launch: 4-pixel sweeps per statistics workgroup (fewer, longer workgroups)
 //   CMAX_NO_FUSED_BLURVAR=1  blurred variance: k_blur_stats_var + k_gimage_blur_adj_var instead of k_blur_stats_adj_var
@@ -2321,6 +2322,8 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // Cap the segment at n / 512 (>= 256 events): cfg1-shaped K3 13 -> 5 us.
     int seg_cap = kSegCut;
     if (h->n < (int64_t)256 * kSegMax) seg_cap = (int)std::min<int64_t>(kSegCut, std::max<int64_t>(256, (h->n + 511) / 512));
+    static const int cap_env = getenv("CMAX_SEG_CAP") ? atoi(getenv("CMAX_SEG_CAP")) : 0;  // tuning only
+    if (cap_env > 0 && free_cut) seg_cap = std::min(kSegCut, cap_env & ~1);
     if (T > 1 && seg_cap < kSparseSegment) max_groups = std::max(max_groups, 3 * T);
     std::vector<int4> segs;
     // Owned groups (batches of at least one full segment per CU whose groups all fit a segment): every group -- empty
