@@ -618,7 +618,7 @@ constexpr int kFoldNone = 0, kFoldStats = 1, kFoldDeferred = 2, kFoldScale = 3; 
 // gradient waits for the statistics: the chain factor is a constant and the mean comes from K1's vote sums (RefArgs::musum)
 constexpr int kFoldStatsInside = 4;
 constexpr int kGradRuns = 0, kGradStrided = 1, kGradOwned = 2, kGradDet = 3, kGradOwnedSmall = 4;  // k_grad's VARIANT (see cmax_event_kernels.inc)
-constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
+[[maybe_unused]] constexpr int kDummy = kWinCap;     // masked path: 64 per-lane scratch words behind the window
 constexpr int kScratch = 200;       // scratch words behind the window; the fast path sends the 2x2 footprint of an
                                     // empty slot to kWinCap + lane + {0, 1, stride, stride + 1}, stride <= 128
 static_assert(kScratch >= 64 + kWinMaxW + 2, "scratch must hold a per-lane 2x2 footprint at the widest stride");
