@@ -457,6 +457,58 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
     return out
 
 
+# DESIGN.md section 5's cost model of one all-reduce of S bytes over N ranks (fully connected xGMI mesh): alpha(N) + S / beta at N = 2
+# (one link), alpha(N) + 2 S / (N beta) from N = 4 on (reduce-scatter + all-gather, every link carries S / N each way)
+COMM_MODEL = {"alpha_us": {2: 12.0, 4: 18.0, 8: 25.0}, "beta_GBps": 100.0}
+
+
+def comm_model_us(nbytes, world):
+    alpha = COMM_MODEL["alpha_us"].get(world, 25.0 if world > 8 else 12.0)
+    wire = nbytes / (COMM_MODEL["beta_GBps"] * 1e3)  # us
+    return alpha + (wire if world <= 2 else 2.0 * wire / world)
+
+
+def comm_probe_run(dev, world, rank, args, reps=50):
+    """N > 1: the collectives of an evaluation measured ON THEIR OWN, beside what DESIGN section 5's model predicts for them, so that one
+    SCALE record confirms or refutes the model.  Sizes: the 16-byte 2-DoF gradient, the 4 KB gradient of the solver's
+    patch objective (2 x 256 doubles), cfg2's single exchange (I, E0, F1 planes), cfg5's C1 (one 1280x720 image) and C2 (its flow
+    gradient).  `reps` back-to-back calls on the stream between two synchronisations, median of 5 such windows, MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    import event_based_optical_flow_amd as E
+    from event_based_optical_flow_amd.distributed import TimeSlicedObjective
+
+    handle = E.CMaxHandle((64, 64))
+    sliced = TimeSlicedObjective(handle, in_library=not args.torch_collectives)
+    in_lib = sliced.collectives.startswith("in-library")
+    sizes = {"grad_2dof_16B": (2, torch.float64), "grad_patch_4KB": (512, torch.float64),
+             "cfg2_single_exchange": (3 * 260 * 346 + 260 + 346, torch.float32), "cfg5_C1_image": (720 * 1280, torch.float32),
+             "cfg5_C2_flow_gradient": (2 * 720 * 1280, torch.float32)}
+    rows = {}
+    for name, (count, dtype) in sizes.items():
+        buf = torch.zeros(count, dtype=dtype, device=dev)
+        op = (lambda: handle.comm_allreduce(buf)) if in_lib else (lambda: dist.all_reduce(buf))
+        for _ in range(5):
+            op()
+        wins = []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                op()
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t0) / reps * 1e6)
+        t = torch.tensor([float(np.median(wins))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        nbytes = count * (8 if dtype == torch.float64 else 4)
+        rows[name] = {"bytes": nbytes, "us": _r(float(t.item())), "model_us": _r(comm_model_us(nbytes, world))}
+    handle.close()
+    return {"collectives": sliced.collectives, "n_ranks": world, "model": COMM_MODEL, "allreduce": rows,
+            "note": "us = measured per call (back-to-back calls on one stream, max over ranks); model_us = DESIGN.md section 5's alpha-beta prediction"}
+
+
 def graph_replay_rate(cfg, ev, motion, dev, steps, windows):
     """The same evaluations replayed from a hipGraph (torch.cuda.CUDAGraph over the library's launches): `steps` evaluations
     per replay, so the host does nothing between them.  Reported NEXT TO `value`, never as it: an optimiser reads loss and
@@ -498,6 +550,61 @@ def graph_replay_rate(cfg, ev, motion, dev, steps, windows):
         return out
     except Exception as e:  # capture not available / refused: report, never fail the bench line
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def _r(x, digits=4):
+    """Round to `digits` significant digits (compact line)."""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def compact_line(out, verbose_path):
+    """The ONE line bench.py prints: the contract's keys, `roofline`, `cpu_baseline` and -- under `configs` -- one short entry per
+    other configuration: {us: microseconds per evaluation, frac: evaluation roofline fraction (SURVEY 8d bytes / time / 8 TB/s),
+    dom_us: the dominant kernel's launch, prep_ms: pack + sort + work list once per batch}.  Everything else (per-kernel
+    dictionaries, window statistics, descriptions, the CPU thread sweep) is in the file named by `verbose`."""
+    r = out["roofline"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 6)
+    c = out["config"]
+    line["config"] = {"workload": c["workload"], "events_per_gpu": c["events_per_gpu"], "image": c.get("image"), "motion_model": c["motion_model"],
+                      "cost": c["cost"], "blur_sigma": c["blur_sigma"], "parallelism": c["parallelism"],
+                      "result_form": c["result_form"].split(" (")[-1].rstrip(")"), "collectives": c["collectives"], "rccl": c["rccl"]}
+    dom = r["dominant"]
+    line["roofline"] = {"bound": "hbm", "achieved": _r(r["achieved"]), "peak": r["peak"], "unit": "GB/s", "frac": _r(r["frac"]),
+                        "traffic": r["traffic"], "algorithmic_bytes": r["algorithmic_bytes_per_evaluation"],
+                        "scope": "one evaluation: B = 24N + 16HW + B_model (SURVEY 8d) / median step time",
+                        "dominant": {"kernel": dom["kernel"].split(" ")[0], "launch_us": _r(dom["launch_us"]), "frac": _r(dom["frac"]),
+                                     "bytes": dom["algorithmic_bytes_per_launch"], "traffic": dom["traffic"]},
+                        "kernels_us": {k: _r(v.get("launch_us", v.get("single_launch_bracket_us"))) for k, v in r["kernels"].items()},
+                        "launch_floor_us": _r(r.get("launch_floor_us")), "frac_raw_form": _r(r.get("frac_raw_form")),
+                        "frac_host_result": _r(r.get("frac_host_result"))}
+    line["timing_us"] = {k: _r(out["timing"][k] * 1e3) for k in ("min", "median", "max")}
+    line["prepare_ms_once_per_batch"] = _r(out["prepare_ms_once_per_batch"])
+    line["loss"] = _r(out["loss"], 8)
+    if out.get("also"):
+        line["configs"] = {k: {"us": _r(a["ms_per_step"] * 1e3), "frac": _r(a["evaluation_frac"]), "dom_us": _r(a["dominant_kernel_us"]),
+                               "prep_ms": _r(a["prepare_ms_once_per_batch"], 3)} for k, a in out["also"].items()}
+        if out["n_gpus"] > 1:
+            for k, a in out["also"].items():
+                line["configs"][k]["value"] = _r(a["value"], 5)
+    if "graph_replay" in out:
+        line["graph_replay_us"] = _r(out["graph_replay"].get("ms_per_step", 0.0) * 1e3) if "ms_per_step" in out["graph_replay"] else None
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                                "cpu_model": cb.get("cpu_model"), "host_cpus": cb.get("host_cpus")}
+    ct = out.get("cpu_baseline_torch")
+    if ct and "value" in ct:
+        line["cpu_baseline_torch"] = {"value": _r(ct["value"]), "unit": "events/s", "cores": ct["cores"], "kind": "port",
+                                      "sample": "oracle/torch_cpu.py (reference-style tensor ops + autograd, fp64), best row of the thread sweep",
+                                      "threads_sweep": {k: _r(v) if not isinstance(v, str) else v[:40] for k, v in ct.get("threads_sweep", {}).items()}}
+    if out.get("comm_probe"):
+        line["comm_probe"] = out["comm_probe"]
+    line["verbose"] = os.path.relpath(verbose_path, ROOT) if os.path.isabs(verbose_path) else verbose_path
+    return line
 
 
 def pin_to_gpu_numa_node(dev_index):
@@ -574,6 +681,9 @@ def main():
                          "finished on the device; raw = cmax_objective_raw where the objective has that form (2-DoF), the consumer folds "
                          "the partial sums; host = cmax_objective_host (every step waits for its numbers)")
     ap.add_argument("--deterministic", action="store_true", help="cmax_set_deterministic(1): integer accumulation, bit-repeatable results (slower)")
+    ap.add_argument("--verbose", action="store_true", help="print the full record (per-kernel dictionaries, every row's windows: ~30 KB) instead "
+                    "of the compact line; the full record is written to --verbose-out either way")
+    ap.add_argument("--verbose-out", default=None, help="file for the full record (default gpurun_out/bench_verbose_<workload>_n<N>.json)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -631,6 +741,13 @@ def main():
                            "kernels_us": {k: v.get("launch_us", v.get("single_launch_bracket_us")) for k, v in r.get("kernels", {}).items()},
                            "collectives": r["collectives"], "prepare_ms_once_per_batch": r["prepare_ms_once_per_batch"]}
 
+    comm_probe = None
+    if world > 1:
+        try:
+            comm_probe = comm_probe_run(dev, world, rank, args)
+        except Exception as e:  # never fail the bench line over a side figure (every rank takes the same path: the probe is collective)
+            comm_probe = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         H, W, n = cfg["H"], cfg["W"], main_res["events_per_gpu"]
         dom = main_res["dominant"]
@@ -684,7 +801,18 @@ def main():
             tc = cpu_baseline_torch(args.workload, cfg, launch_affinity)
             if tc is not None:
                 out["cpu_baseline_torch"] = tc
-        print(json.dumps(out), flush=True)
+        if comm_probe is not None:
+            out["comm_probe"] = comm_probe
+        # The full record goes to a file; stdout carries ONE compact line (the verbose line was ~30 KB and the driver
+        # keeps the last 8 KB of stdout, so the rows for cfg3 / cfg4 / cfg5 / cfg5_strong / hbm never reached BENCH_r04.json).
+        vpath = args.verbose_out or os.path.join(ROOT, "gpurun_out", "bench_verbose_%s_n%d.json" % (args.workload, world))
+        try:
+            os.makedirs(os.path.dirname(vpath), exist_ok=True)
+            with open(vpath, "w") as f:
+                json.dump(out, f)
+        except OSError as e:
+            vpath = "not written: %s" % e
+        print(json.dumps(out if args.verbose else compact_line(out, vpath)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

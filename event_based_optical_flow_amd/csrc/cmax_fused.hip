@@ -186,7 +186,7 @@ struct cmax_handle_s {
     int *cursor = nullptr;  // [nkeys] per-tile cursor of the bucket pass, then active source pixels per tile
     int *scan_tmp = nullptr;  // [ceil(nkeys / 2048)] chunk sums of the scan
     int nkeys = 0, ntr = 0, ntc = 0;
-    int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] source pixels with >= 1 event
+    int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] events kept from off the sensor (cmax_set_keep_outside)
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
     bool mid = false;        // MID segments: up to 3064 events, four source tiles (five (tile, bin) groups) wide, event kernels of the m512 namespace -- when the
                              // standard cut would need more workgroups than the chip holds at once and this one does not (build_segments)
@@ -2166,7 +2166,7 @@ static int pad_event_tail(cmax_handle_s *h, hipStream_t s) {
 }
 
 // host copy of what one batch left on the device: [0] any fractional source coordinate, [1] dropped events,
-// [2] source pixels with >= 1 event (un-binned order only); batch time extremes
+// [2] events kept from off the sensor (cmax_set_keep_outside); batch time extremes
 struct BatchReadback {
     int flags[4] = {0, 0, 0, 0};
     double tmm[2] = {0.0, 0.0};
@@ -2405,17 +2405,21 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         dev_free(&h->d_segs);
         dev_free(&h->d_gpart);
         dev_free(&h->d_win);
-    dev_free(&h->d_shifts);
-    dev_free(&h->bimg);
-    dev_free(&h->braw);
-    dev_free(&h->bwin);
-    dev_free(&h->bshifts);
         dev_free(&h->d_shifts);
+        // the workspace of cmax_objective_batch is sized by the work list too: allocated again on its next call
+        dev_free(&h->bimg);
+        dev_free(&h->braw);
+        dev_free(&h->bwin);
+        dev_free(&h->bshifts);
+        h->batch_cap = h->batch_seg_cap = 0;
+        h->seg_cap = 0;
         int rc = dev_alloc(h, &h->d_segs, h->nseg);
         if (!rc) rc = dev_alloc(h, &h->d_win, (int64_t)4 * h->nseg);
         if (!rc) rc = dev_alloc(h, &h->d_shifts, (int64_t)4 * h->nseg * kShiftWordsMax);
         if (!rc) rc = dev_alloc(h, &h->d_gpart, (int64_t)4 * h->nseg * 2);
         if (rc) return rc;
+        // (K3 reads an offset word only where K1 flagged its block; cleared once so that no word ever holds allocator garbage)
+        CMAX_CHECK_HIP(hipMemsetAsync(h->d_shifts, 0, (size_t)4 * h->nseg * kShiftWordsMax * sizeof(unsigned), s));
         h->seg_cap = h->nseg;
     }
     if (h->nseg > 0) {
@@ -2640,6 +2644,11 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->scan_tmp);
     dev_free(&h->d_segs);
     dev_free(&h->d_win);
+    dev_free(&h->d_shifts);
+    dev_free(&h->bimg);
+    dev_free(&h->braw);
+    dev_free(&h->bwin);
+    dev_free(&h->bshifts);
     dev_free(&h->evp);
     dev_free(&h->rx);
     dev_free(&h->ry);
@@ -2696,6 +2705,7 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         CMAX_CHECK_LAUNCH();
     }
     h->n_time_bin = n_time_bin;
+    h->slab_major = false;  // the slab order is a property of the batch cmax_set_time_slabs re-ordered, not of the handle
     if (n == 0) {
         CMAX_CHECK_HIP(hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
         h->has_frac = false;
@@ -2709,13 +2719,22 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
     return sort_events(h, RawSource<double>{(const double *)events, h->d_tmm, h->H, h->W, keyed, keep}, n, keyed != 0, 0, s);
 }
 
+// Re-ordering the packed events (time bins, time slabs) makes a new work list but NOT a new batch: the events the batch dropped /
+// kept from off the sensor were counted by cmax_set_events from the raw input; the re-sort reads the packed SoA with those flags
+// cleared and must not overwrite the counts (the guards of the dense / voxel objectives read n_outside)
+static void bump_generation_keep_counts(cmax_handle_s *h) {
+    const bool counted = h->generation_counted == h->generation;
+    ++h->generation;
+    if (counted) h->generation_counted = h->generation;
+}
+
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     CMAX_REQUIRE(h != nullptr, "set_time_bins: handle");
     CMAX_REQUIRE(n_time_bin >= 0 && n_time_bin <= 255, "set_time_bins: n_time_bin must be in 0..255");
     if (n_time_bin == h->n_time_bin && !h->slab_major) return 0;
     h->n_time_bin = n_time_bin;
     h->slab_major = false;
-    ++h->generation;
+    bump_generation_keep_counts(h);
     if (h->n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // re-order the packed events in place (through the staging SoA); [0] "fractional sources" stays what it was
@@ -2730,7 +2749,7 @@ int cmax_set_time_slabs(cmax_handle_t h, int n_slab, cmax_stream_t stream) {
     if (n_slab == h->n_time_bin && h->slab_major) return 0;
     h->n_time_bin = n_slab;
     h->slab_major = n_slab > 0;
-    ++h->generation;
+    bump_generation_keep_counts(h);
     if (h->n == 0) return 0;
     return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, (hipStream_t)stream);
 }
@@ -3423,11 +3442,13 @@ int cmax_objective_batch(cmax_handle_t h, const cmax_objective_t *d, const void 
         dev_free(&h->bwin);
         dev_free(&h->bshifts);
         const int cap = std::max(K, h->batch_cap), scap = std::max(h->nseg, h->batch_seg_cap);
+        h->batch_cap = h->batch_seg_cap = 0;  // (a failed allocation below must not leave a later call believing the workspace is there)
         rc = dev_alloc(h, &h->bimg, (int64_t)2 * cap * 4 * npix);
         if (!rc) rc = dev_alloc(h, &h->braw, (int64_t)cap * 4 * kRawStride);
         if (!rc) rc = dev_alloc(h, &h->bwin, (int64_t)cap * 4 * scap);
         if (!rc) rc = dev_alloc(h, &h->bshifts, (int64_t)cap * 4 * scap * kShiftWordsMax);
         if (rc) return rc;
+        CMAX_CHECK_HIP(hipMemsetAsync(h->bshifts, 0, (size_t)cap * 4 * scap * kShiftWordsMax * sizeof(unsigned), s));
         h->batch_cap = cap;
         h->batch_seg_cap = scap;
         h->batch_zero[0] = h->batch_zero[1] = 0;

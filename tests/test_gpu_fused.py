@@ -719,3 +719,40 @@ def test_objective_batch_falls_back_for_other_objectives():
         r1, g1 = h.evaluate(desc, flows[k])
         assert abs(r1[0].item() - res[k, 0].item()) <= 1e-6 * abs(r1[0].item())
         assert rel_max(grad[k].cpu().numpy(), g1.cpu().numpy()) <= 2e-5
+
+
+def test_rebinning_keeps_the_batch_counts_and_set_events_leaves_slab_order():
+    """ADVICE r4.  (1) cmax_set_time_bins / cmax_set_time_slabs re-sort the PACKED events: the counts cmax_set_events took from the raw
+    input (events dropped, events kept from off the sensor) must survive, or the guards of the dense / voxel objectives are bypassed and
+    such events are warped as if they sat on the nearest sensor pixel.  (2) the slab order belongs to the batch that was re-ordered: a
+    later cmax_set_events on the same handle starts un-slabbed (voxel objectives and the patch search work again)."""
+    size, n = (64, 96), 40_000
+    rng = np.random.default_rng(5)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=5)
+    ev[:300, 0] = -rng.uniform(1.0, 9.0, 300)  # 300 events above the sensor
+    ev[300:303, 1] = np.nan                    # three unusable ones
+    h = E.CMaxHandle(size).set_keep_outside(True).set_events(ev, on_dropped="ignore")
+    info0 = h.batch_info()
+    assert info0["outside"] == 300 and info0["dropped"] == 3
+    flow = E.utils.generate_smooth_flow(size, 3, seed=6)
+    dense = E.make_descriptor("image_variance", "dense-flow")
+    for rebin in (lambda: h.set_time_bins(4), lambda: h.set_time_slabs(2), lambda: h.set_time_bins(0)):
+        rebin()
+        info = h.batch_info()
+        assert info["outside"] == 300 and info["dropped"] == 3 and info["packed"] == n - 3, info
+        with pytest.raises(E._lib.CmaxError):  # a flow has no value off the sensor: refused, not clamped
+            h.evaluate(dense, flow)
+    # (2) slabs, then a new batch with time bins on the same handle: voxel objectives must work
+    h2 = E.CMaxHandle(size).set_events(ev[303:])
+    h2.set_time_slabs(2)
+    ev2 = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=7)
+    h2.set_events(ev2, time_bin=4)
+    voxel = np.stack([flow * (1.0 + 0.1 * k) for k in range(4)])
+    res, grad = h2.evaluate(E.make_descriptor("image_variance", "dense-flow-voxel", time_bin=4), voxel)
+    ref = orc.objective(ev2, np.asarray(voxel, np.float32).astype(np.float64), "dense-flow-voxel", size, cost="image_variance", sigma=0)
+    assert abs(res[0].item() - ref["loss"]) <= 1e-4 * abs(ref["loss"])
+    assert np.abs(grad.double().cpu().numpy() - ref["grad"]).max() <= 1e-4 * np.abs(ref["grad"]).max()
+    h2.set_time_slabs(2)
+    h2.set_events(ev2)  # un-binned batch after a slabbed one: the patch search walks tile-major groups again
+    loss, gm, count = h2.patch_search(np.array([[0, 32, 0, 48]]), (32, 48), np.zeros((1, 1, 2)), 1.0)
+    assert int(count[0].item()) > 0

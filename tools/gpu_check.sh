@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
 timeout 1200 python -m pytest tests -m gpu -q --maxfail=20 ${PYTEST_ARGS} > gpurun_out/pytest.log 2>&1; echo "pytest rc=$?"; tail -${PYTEST_TAIL:-15} gpurun_out/pytest.log
 for wl in ${WORKLOADS:-cfg2}; do
-  timeout 600 python bench.py --workload $wl --steps ${STEPS:-200} --warmup 20 ${BENCH_ARGS} > gpurun_out/bench_$wl.log 2>&1; echo "bench $wl rc=$?"
+  timeout 600 python bench.py --verbose --workload $wl --steps ${STEPS:-200} --warmup 20 ${BENCH_ARGS} > gpurun_out/bench_$wl.log 2>&1; echo "bench $wl rc=$?"
   python - <<PY
 import json
 for line in open("gpurun_out/bench_$wl.log"):
