@@ -84,6 +84,7 @@ class CMaxHandle:
                                     ctypes.byref(self._h)))
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.time_bin = 0
+        self.time_slabs = 0  # cmax_set_time_slabs order of the current batch (0: none); reset by set_events / set_time_bins
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -102,8 +103,12 @@ class CMaxHandle:
     finds_time_extremes = True  # set_events(ev, None, None, ...) reduces t_min / t_max on the device
 
     def set_keep_outside(self, on: bool = True):
-        """Keep finite events whose source pixel lies OFF the sensor (cmax_set_keep_outside; next set_events on): the reference's
-        2-DoF warp lets them vote wherever they warp into the padded image (src/warp.py:506-515).  2-DoF objectives only."""
+        """Finite events whose source pixel lies OFF the sensor (cmax_set_keep_outside; takes effect with the next set_events).
+        True -- THE DEFAULT since round 5 -- keeps them: the reference's 2-DoF warp has no bounds test on the source and lets such an
+        event vote wherever it warps into the padded image (src/warp.py:506-515); a dense / voxel objective (a flow has no value off
+        the sensor; the reference's gather indexes out of bounds there, src/warp.py:303-307) and the patch search then REFUSE the
+        batch.  False drops them while packing (counted: batch_info()["dropped"], on_dropped) -- what a caller of a dense objective
+        asks for explicitly; the pyramid solver does, with on_dropped="raise"."""
         check(self._lib.cmax_set_keep_outside(self._h, int(bool(on))))
         return self
 
@@ -126,6 +131,7 @@ class CMaxHandle:
                                         float(tmin) if have else 0.0, float(tmax) if have else 0.0, int(time_bin),
                                         F._stream()))
         self.time_bin = int(time_bin)
+        self.time_slabs = 0
         dropped = self.batch_info()["dropped"] if on_dropped != "ignore" else 0
         if dropped and on_dropped == "raise":
             raise ValueError(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events whose source pixel is outside the "
@@ -155,12 +161,28 @@ class CMaxHandle:
     def set_time_bins(self, time_bin: int):
         check(self._lib.cmax_set_time_bins(self._h, int(time_bin), F._stream()))
         self.time_bin = int(time_bin)
+        self.time_slabs = 0
 
     def set_time_slabs(self, n_slab: int):
         """Large motions of a 2-DoF / dense objective: order the batch in `n_slab` time slabs (cmax_set_time_slabs); <= 1 undoes it."""
         check(self._lib.cmax_set_time_slabs(self._h, int(n_slab), F._stream()))
         self.time_bin = 0
+        self.time_slabs = int(n_slab) if n_slab > 1 else 0
         return self
+
+    def auto_time_slabs(self, displacement_px: float) -> int:
+        """Put the batch into the slab order `suggest_time_slabs(displacement_px)` asks for -- with hysteresis, so that an optimiser whose
+        motion hovers around a threshold does not re-sort the batch every iteration: more slabs as soon as the displacement asks for
+        them (an un-slabbed 150-px evaluation costs 4x a slabbed one), fewer only once it has fallen to 0.6 of the threshold that
+        would keep the current count.  What the solver classes call before every evaluation (the motion is theirs, on the host; the
+        library never reads a motion back).  Binned (voxel) handles are left alone.  Returns the slab count in force."""
+        if self.time_bin > 0:
+            return 0
+        want = self.suggest_time_slabs(displacement_px)
+        cur = max(self.time_slabs, 1)
+        if want > cur or (want < cur and self.suggest_time_slabs(displacement_px / 0.6) < cur):
+            self.set_time_slabs(want)
+        return self.time_slabs
 
     def suggest_time_slabs(self, displacement_px: float) -> int:
         """Slab count for a motion of up to `displacement_px` over the batch (profiles/r04_large_motion.txt: 1M events @346x260 --
@@ -671,6 +693,30 @@ class ContrastObjective:
         if out is None:
             out = torch.zeros_like(vector, dtype=torch.float64)
         return out.reshape(vector.shape).to(vector.dtype if vector.dtype.is_floating_point else torch.float64)
+
+    def evaluate_candidates(self, motions, coarse_flows=None) -> torch.Tensor:
+        """Loss of K candidate motions `motions` [K, ...] -> float64 [K] on the device: one cmax_objective_batch call per fused term
+        (the reference's gradient-free paths score batches of sampled motions, src/solver/base.py:738-758,
+        src/solver/patch_contrast_base.py:126-187).  total_variation members act on `coarse_flows` [K, 2, ph, pw]; for a 2-DoF
+        translation the reference hands them a [2, 1, 1] flow, whose total variation is 0: they may be omitted there."""
+        mt = to_device_tensor(motions, "motions").detach()
+        K = int(mt.shape[0])
+        loss = torch.zeros(K, dtype=torch.float64, device=self.handle.device)
+        for name, weight, desc in self.terms:
+            if desc is None:
+                if coarse_flows is None:
+                    if F.MODEL_CODES[self.motion_model] == _lib.MODEL_2DOF:
+                        continue
+                    raise KeyError("flow")
+                cf = to_device_tensor(coarse_flows, "flow")
+                value = torch.stack([F.total_variation(cf[k], self.omit_boundary) for k in range(K)]).to(torch.float64)
+                if self.direction != "minimize":
+                    value = -value
+            else:
+                results, _ = self.handle.evaluate_batch(desc, mt)
+                value = results[:, 0]
+            loss = loss + combine(weight, value)
+        return loss
 
     def __call__(self, motion: torch.Tensor, coarse_flow: Optional[torch.Tensor] = None) -> torch.Tensor:
         loss = 0.0

@@ -167,7 +167,7 @@ struct cmax_handle_s {
     int device = 0;
     int64_t n = 0, cap = 0;
     int64_t n_dropped = 0;  // events of the last batch whose source pixel was off the sensor (or NaN): not packed
-    bool keep_outside = false;  // cmax_set_keep_outside: finite events off the sensor are packed (nearest sensor pixel + residual)
+    bool keep_outside = true;  // cmax_set_keep_outside (default since round 5): finite events off the sensor are packed (nearest sensor pixel + residual)
     int64_t n_outside = 0;      // ... how many of the last batch (2-DoF objectives only: a flow has no value there)
     bool has_frac = false;
     int n_time_bin = 0;
@@ -2796,7 +2796,7 @@ static int check_objective_args(cmax_handle_t h, const cmax_objective_t *d, cons
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || (d->T > 0 && d->T == h->n_time_bin), "objective: voxel T must match the handle's time bins");
     CMAX_REQUIRE(d->model != CMAX_MODEL_VOXEL || !h->slab_major, "objective: a voxel motion needs time BINS (cmax_set_time_bins), this handle is in slab order");
     CMAX_REQUIRE(d->model == CMAX_MODEL_2DOF || h->n_outside == 0,
-                 "objective: the batch holds events off the sensor (cmax_set_keep_outside): only the 2-DoF model is defined for them -- a flow has no value there");
+                 "objective: the batch holds events off the sensor: only the 2-DoF model is defined for them -- a flow has no value there (cmax_set_keep_outside(h, 0) before cmax_set_events drops them)");
     CMAX_REQUIRE(!d->omit_boundary || (h->Hp > 2 && h->Wp > 2), "objective: image too small for omit_boundary");
     CMAX_REQUIRE((int64_t)(d->model == CMAX_MODEL_VOXEL ? d->T : 1) * 2 * h->H * h->W * 4 < ((int64_t)1 << 32),
                  "objective: the motion field must be smaller than 4 GiB (32-bit byte offsets in the event kernels)");
@@ -4079,7 +4079,6 @@ int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h,
         if (rc) return rc;
         h->search_cap = n_patch;
     }
-    CMAX_REQUIRE(!h->slab_major, "patch_search: the handle is in slab order (cmax_set_time_slabs); the search walks tile-major groups");
     CMAX_REQUIRE(h->n_outside == 0, "patch_search: the batch holds events off the sensor (cmax_set_keep_outside)");
     SearchArgs a;
     a.evp = h->evp;
@@ -4090,6 +4089,7 @@ int cmax_patch_search(cmax_handle_t h, int n_patch, const int *boxes, int img_h,
     a.ntr = h->ntr;
     a.ntc = h->ntc;
     a.has_frac = h->has_frac ? 1 : 0;
+    a.slab_major = h->slab_major && h->n_time_bin > 0 ? 1 : 0;
     a.boxes = (const int4 *)boxes;
     a.img_h = img_h;
     a.img_w = img_w;

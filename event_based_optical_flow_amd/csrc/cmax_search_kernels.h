@@ -32,14 +32,24 @@ struct SearchArgs {
     const float *rx, *ry;  // fractional parts of the source coordinates (read only when has_frac)
     const int *tile_start;  // first sorted event of every group
     int groups_per_tile, ntr, ntc, has_frac;
+    int slab_major;  // the groups are ordered (tile row, time slab, tile column) -- cmax_set_time_slabs -- instead of (tile row, tile column, bin)
     const int4 *boxes;  // [n_patch] (x_min, x_max, y_min, y_max): x_min <= x < x_max, rows first
     int img_h, img_w;   // the patch image the reference's imager of this scale allocates
 };
 
-// events of tile row `tr` inside the box's tile columns
-__device__ __forceinline__ void search_row_range(const SearchArgs &a, int tr, int tc0, int tc1, int &begin, int &end) {
+// events of tile row `tr` inside the box's tile columns: ONE contiguous range in tile-major order (a tile's time bins follow each
+// other), one range per time slab `sl` in slab-major order (round 5: the solver keeps large-motion batches in slab order and
+// re-initialises its finer scales from the same handle)
+__device__ __forceinline__ int search_row_parts(const SearchArgs &a) { return a.slab_major ? a.groups_per_tile : 1; }
+__device__ __forceinline__ void search_row_range(const SearchArgs &a, int tr, int sl, int tc0, int tc1, int &begin, int &end) {
     if (tc1 < tc0) {  // box entirely outside the sensor
         begin = end = 0;
+        return;
+    }
+    if (a.slab_major) {
+        const int row = (tr * a.groups_per_tile + sl) * a.ntc;
+        begin = a.tile_start[row + tc0];
+        end = a.tile_start[row + tc1 + 1];
         return;
     }
     begin = a.tile_start[(tr * a.ntc + tc0) * a.groups_per_tile];
@@ -55,9 +65,9 @@ __global__ void __launch_bounds__(kSearchThreads) k_search_range(SearchArgs a, f
     int cnt = 0;
     if (box.y > box.x && box.w > box.z) {
         const int tr0 = max(box.x, 0) >> 4, tr1 = min((box.y - 1) >> 4, a.ntr - 1), tc0 = max(box.z, 0) >> 4, tc1 = min((box.w - 1) >> 4, a.ntc - 1);
-        for (int tr = tr0; tr <= tr1; ++tr) {
+        for (int part = 0; part < (tr1 - tr0 + 1) * search_row_parts(a); ++part) {
             int begin, end;
-            search_row_range(a, tr, tc0, tc1, begin, end);
+            search_row_range(a, tr0 + part / search_row_parts(a), part % search_row_parts(a), tc0, tc1, begin, end);
             for (int i = begin + (int)threadIdx.x; i < end; i += kSearchThreads) {
                 const uint2 e = a.evp[i];
                 const int x = (int)(e.x & 0xFFFu), y = (int)((e.x >> 12) & 0xFFFu);
@@ -136,9 +146,9 @@ k_patch_search(SearchArgs a, const float2 *__restrict__ range, int n_cand, const
     const bool zero_span = c < n_cand && !(tr.y > tr.x);
     if (box.y > box.x && box.w > box.z && !zero_span) {
         const int tr0 = max(box.x, 0) >> 4, tr1 = min((box.y - 1) >> 4, a.ntr - 1), tc0 = max(box.z, 0) >> 4, tc1 = min((box.w - 1) >> 4, a.ntc - 1);
-        for (int trow = tr0; trow <= tr1; ++trow) {
+        for (int part = 0; part < (tr1 - tr0 + 1) * search_row_parts(a); ++part) {
             int begin, end;
-            search_row_range(a, trow, tc0, tc1, begin, end);
+            search_row_range(a, tr0 + part / search_row_parts(a), part % search_row_parts(a), tc0, tc1, begin, end);
             for (int i = begin + (int)threadIdx.x; i < end; i += kSearchThreads) {
                 const uint2 e = a.evp[i];
                 const int x = (int)(e.x & 0xFFFu), y = (int)((e.x >> 12) & 0xFFFu);

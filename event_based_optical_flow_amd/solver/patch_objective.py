@@ -44,6 +44,7 @@ class PatchFlowObjective:
         model = "dense-flow-voxel" if self.time_aware else "dense-flow"
         self.contrast = ContrastObjective(handle, model, cost=cost, cost_with_weight=cost_with_weight, sigma=blur_sigma)
         self.device = handle.device  # read by scipy_autograd.TorchWrapper
+        self.auto_slabs = True  # ensure_time_slabs: time-slab order of the batch follows the motion's size
         self._plan = None
         self._build_native_plan()
 
@@ -104,11 +105,23 @@ class PatchFlowObjective:
         """TorchWrapper calls `value_and_grad_numpy` / `hvp_numpy` when this is True."""
         return self._plan is not None
 
+    def ensure_time_slabs(self, x) -> int:
+        """Large motions (round 5): before an evaluation at patch motion `x` the batch is put into the time-slab order its displacement
+        over the batch asks for (max |x| * t_scale pixels; CMaxHandle.auto_time_slabs: thresholds with hysteresis, so a converging
+        optimiser re-sorts at most a few times per scale).  The shipped configs draw their coarsest start from +-150 px per unit time
+        (configs/*.yaml optimizer.parameters, initialize_random); un-slabbed, a 150-px evaluation of a 1M-event batch costs 4x a
+        slabbed one (profiles/r04_large_motion.txt).  Time-aware objectives keep their time bins."""
+        if self.time_aware or not self.auto_slabs:
+            return 0
+        xm = float(x.detach().abs().max()) if isinstance(x, torch.Tensor) else float(np.abs(x).max())
+        return self.handle.auto_time_slabs(xm * abs(self.t_scale))
+
     def value_and_grad_numpy(self, x: np.ndarray, with_tv: bool = True, want_grad: bool = True):
         """x [2*ph*pw] float64 (host) -> (loss, gradient [2*ph*pw] float64): one cmax_patch_plan_evaluate call."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         if x.size != self._nx:
             raise ValueError(f"x has {x.size} elements, the patch grid needs {self._nx}")
+        self.ensure_time_slabs(x)
         loss = ctypes.c_double(0.0)
         grad = np.empty(self._nx, dtype=np.float64) if want_grad else None
         with torch.cuda.device(self.handle.device):
@@ -123,6 +136,7 @@ class PatchFlowObjective:
         analytic gradient of the smooth part, as in `hvp` (kept for cross-checks)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
+        self.ensure_time_slabs(x)
         if self.time_aware and not exact:
             vmax = float(np.abs(v).max())
             if vmax == 0.0:
@@ -212,4 +226,5 @@ class PatchFlowObjective:
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         x = x.to(self.handle.device)
+        self.ensure_time_slabs(x)
         return self.contrast(self.dense_flow(x), x.reshape((2,) + self.patch_image_size))

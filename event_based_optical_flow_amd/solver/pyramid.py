@@ -28,6 +28,7 @@ import scipy.ndimage as ndi
 from ..cmax import CMaxHandle
 from . import scipy_autograd
 from .patch_objective import PatchFlowObjective
+from .translation_search import ONE_PATCH_FIELD, WHOLE_IMAGE_FIELD, grid_search_translation
 
 logger = logging.getLogger(__name__)
 
@@ -135,13 +136,14 @@ class PyramidalPatchContrastMaximization:
         # one handle and one objective per scale for the life of the solver: the device workspaces, the sorted-event
         # buffers and the native plans are reused from frame to frame (main.py runs one solver over a whole sequence)
         if self._handle is None:
-            self._handle = CMaxHandle(self.image_shape, self.padding)
-        # on_dropped="raise" (VERDICT r3 #8): an event whose source pixel is off the sensor cannot be kept by the fused path, while the
-        # reference's 2-DoF warp lets it vote when it lands in a padded image (src/warp.py:506-520, src/event_image_converter.py:355-372)
-        # and its dense warp indexes the flow out of bounds there (src/warp.py:303-307) -- a solver must not diverge from it silently
+            # the per-scale objective warps with a DENSE flow: an event whose source pixel is off the sensor has no flow value (the
+            # reference's gather indexes out of bounds there, src/warp.py:303-307) -- asked to be dropped while packing, and ...
+            self._handle = CMaxHandle(self.image_shape, self.padding).set_keep_outside(False)
+        # ... on_dropped="raise" (VERDICT r3 #8): a solver must not diverge from the reference silently
         handle = self._handle.set_events(events, time_bin=self.time_bin, on_dropped="raise")
         t = events[:, 2]
         t_scale = float(t.max() - t.min()) if self.normalize_t_in_batch else 1.0
+        self.slab_history = []  # (scale, slab count in force when the scale's optimisation ended): large motions, DESIGN section 2
         best: Dict[int, np.ndarray] = {}
         self.history = []
         self.search_history = []
@@ -165,6 +167,12 @@ class PyramidalPatchContrastMaximization:
                 x0 = self.initialize_guess_from_patch_search(handle, s, x0)
             elif self.slv_config["patch"]["initialize"] == "zero":
                 x0 = np.zeros(2 * self.scaled_n_patch[s])
+            elif self.slv_config["patch"]["initialize"] == "global-best":  # patch_contrast_pyramid.py:292-297
+                best_guess = self.initialize_guess_from_whole_image(handle, t_scale)
+                x0 = np.tile(best_guess[None], (self.scaled_n_patch[s], 1)).T.reshape(-1)
+            elif self.slv_config["patch"]["initialize"] == "grid-best":  # patch_contrast_pyramid.py:298-305
+                best_guess = self.initialize_guess_from_patch(events, s, self.scaled_n_patch[s] // 2 - 1)
+                x0 = np.tile(best_guess[None], (self.scaled_n_patch[s], 1)).T.reshape(-1)
             else:
                 x0 = self.initialize_random(self.scaled_n_patch[s]).reshape(-1)
             res = scipy_autograd.minimize(objective, x0, method=self.opt_method, precision="float64",
@@ -174,9 +182,47 @@ class PyramidalPatchContrastMaximization:
                                           else {"maxiter": self.opt_config["max_iter"]})
             logger.info(f"Scale {s}: loss {res.fun}")
             self.history.append((s, res))
+            self.slab_history.append((s, handle.time_slabs))
             best[s] = np.asarray(res.x).reshape((2,) + pis)
         self._last_handle, self._last_t_scale = handle, t_scale
         return self.update_coarse_from_fine(best)
+
+    # -- grid initialisers of the coarsest scale: K candidates per library call ------------------------------------------
+    def _search_cost(self) -> dict:
+        return {"cost": self.cost_name, "cost_with_weight": self.cost_weight, "sigma": self.iwe_config["blur_sigma"]}
+
+    def initialize_guess_from_whole_image(self, handle: CMaxHandle, t_scale: float) -> np.ndarray:
+        """patch.initialize: "global-best" (src/solver/patch_contrast_base.py:164-187): the best of the 30 x 30 translations
+        np.arange(-150, 150, 10)^2 for the WHOLE batch under the solver's own cost, warped as one 2-DoF motion (`motion * t_scale`,
+        objective_scipy_for_patch 244-271).  900 objective evaluations in the reference, 900 / 32 cmax_objective_batch calls here,
+        the batch in time slabs while the candidates are large (CMaxHandle.auto_time_slabs)."""
+        if self.is_time_aware:
+            raise NotImplementedError("global-best initialisation on a time-binned handle is not built (the 2-DoF search wants slabs)")
+        # a 2-DoF warp would keep events from off the sensor; this handle dropped them on request (and raised if there were any)
+        guess, loss = grid_search_translation(handle, t_scale, WHOLE_IMAGE_FIELD, **self._search_cost())
+        self.search_history.append((self.coarest_scale, "global-best", loss, guess))
+        logger.info(f"Initial value: best_guess = {guess}")
+        return guess
+
+    def initialize_guess_from_patch(self, events: np.ndarray, s: int, patch_index: int) -> np.ndarray:
+        """patch.initialize: "grid-best" (src/solver/patch_contrast_base.py:126-162): np.arange(-150, 150, 30)^2 on the events of ONE
+        patch (utils.crop_event with the patch's bounds), its own time span as t_scale; warper and imager stay full-size."""
+        if self.is_time_aware:
+            raise NotImplementedError("grid-best initialisation on a time-binned handle is not built")
+        x0, x1, y0, y1 = self.patch_boxes(s)[patch_index]
+        m = (x0 <= events[:, 0]) & (events[:, 0] < x1) & (y0 <= events[:, 1]) & (events[:, 1] < y1)
+        cropped = events[m]
+        if len(cropped) == 0:  # "No events in the patch": every loss is 0, the first candidate wins
+            return np.array([float(ONE_PATCH_FIELD[0]), float(ONE_PATCH_FIELD[0])])
+        t_scale = float(cropped[:, 2].max() - cropped[:, 2].min()) if self.normalize_t_in_batch else 1.0
+        sub = CMaxHandle(self.image_shape, self.padding).set_events(cropped)
+        try:
+            guess, loss = grid_search_translation(sub, t_scale, ONE_PATCH_FIELD, **self._search_cost())
+        finally:
+            sub.close()
+        self.search_history.append((s, "grid-best", loss, guess))
+        logger.info(f"Initial value: best_guess = {guess}")
+        return guess
 
     def patch_boxes(self, s: int) -> np.ndarray:
         """[n_patch, 4] = x_min, x_max, y_min, y_max of scale s: FlowPatch bounds (src/types/flow_patch.py:29-42) of the

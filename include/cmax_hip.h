@@ -199,8 +199,9 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream);
  * tile row -- (tile row, slab, tile column) -- so that a segment's events span 1/n_slab of the batch's duration and its LDS window is
  * the tiles' extent plus 1/n_slab of the displacement range (a window that would overflow at 150 px over the batch fits again; see
  * DESIGN.md section 4 "large motions").  Results are those of the un-binned order (same events, same arithmetic; the sums are
- * associated differently).  Voxel objectives and cmax_patch_search need cmax_set_time_bins order and refuse a slab handle;
- * n_slab <= 1 returns to the un-binned order.  Blocks once like cmax_set_time_bins.                                              */
+ * associated differently).  Voxel objectives need cmax_set_time_bins order and refuse a slab handle (cmax_patch_search walks either
+ * order since round 5); n_slab <= 1 returns to the un-binned order; the next cmax_set_events starts un-slabbed again.  Blocks once
+ * like cmax_set_time_bins.                                                                                                        */
 int cmax_set_time_slabs(cmax_handle_t h, int n_slab, cmax_stream_t stream);
 
 /* Image of warped events for one reference time (fp32 [Hp,Wp], blurred if sigma > 0).
@@ -422,8 +423,9 @@ int cmax_batch_info(cmax_handle_t h, int64_t *n_packed, int64_t *n_dropped, int 
  * r px carries ulp(r) / 2 of rounding: 4e-6 px at 100 px).  cmax_batch_outside reports how many the last batch held; they count as
  * packed, not as dropped.  Only the 2-DoF model (and the un-warped image) is defined for them: a dense / voxel objective, cmax_iwe of
  * those models and cmax_patch_search refuse a batch that holds any (CMAX_EINVAL) -- the reference indexes its flow with the source
- * pixel there (negative indices wrap around in torch; nothing a caller can mean).  Default: off (events off the sensor are dropped
- * and counted, as in rounds 1-3).                                                                                               */
+ * pixel there (negative indices wrap around in torch; nothing a caller can mean).  Default since round 5: ON -- a handle follows the
+ * function cited above; cmax_set_keep_outside(h, 0) asks for such events to be dropped (and counted: cmax_batch_info) while packing,
+ * which is what a caller of a dense / voxel objective on such a batch has to say explicitly.                                     */
 int cmax_set_keep_outside(cmax_handle_t h, int on);
 int cmax_batch_outside(cmax_handle_t h, int64_t *n_outside);
 /* The work list cmax_set_events / cmax_set_time_bins cut for the event kernels (one workgroup per segment): number of

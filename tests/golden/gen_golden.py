@@ -828,6 +828,58 @@ def gen_outside_sensor():
     np.savez_compressed(os.path.join(HERE, "outside_sensor.npz"), **out)
 
 
+def gen_global_best():
+    """patch.initialize "global-best" / "grid-best" of the reference's pyramid solver (src/solver/patch_contrast_pyramid.py:292-305):
+    initialize_guess_from_whole_image / initialize_guess_from_patch (src/solver/patch_contrast_base.py:164-187, 126-162) RUN on a
+    moving-dot scene with the shipped YAML cost -- the reference's pick -- plus the loss of every grid candidate, obtained from the
+    same objective_scipy_for_patch the two functions loop over (so a near-tie can be told from a disagreement).
+    The batch lasts 0.4 s: the +-150 px/s box of the grid is +-60 px of displacement (a large-motion search)."""
+    rng = np.random.default_rng(SEED + 9)
+    H, W = 68, 90
+    period = 0.4
+
+    def flow_fn(cx, cy):  # pixel per batch period: ~ (24, -12) px = (60, -30) px / s
+        return 24.0 + 0.0 * cx, -12.0 + 0.0 * cy
+
+    ev = _moving_dot_events(12000, H, W, flow_fn, rng, n_dots=120, period=period)
+    ev[0, 2], ev[-1, 2] = 0.0, period
+    slv = _ref_pyramid_solver(H, W, False)
+    slv.overload_patch_configuration(1)
+    out = {"events": ev, "image_size": np.array([H, W]), "period": np.array(period)}
+
+    def losses(events_np, field):
+        slv.events = torch.from_numpy(events_np).double().requires_grad_().to(slv._device)
+        grid = np.zeros((len(field), len(field)))
+        for i in range(len(field)):
+            for j in range(len(field)):
+                guess = torch.from_numpy(np.array([field[i], field[j]])).double().requires_grad_().to(slv._device)
+                grid[i, j] = float(slv.objective_scipy_for_patch(guess, suppress_log=True))
+        return grid
+
+    import logging
+    logging.disable(logging.INFO)  # the two functions log every candidate
+    field_w = np.arange(-150, 150, 10)
+    best_w = slv.initialize_guess_from_whole_image(ev)
+    out["whole__field"] = field_w
+    out["whole__best"] = best_w.detach().cpu().numpy() if isinstance(best_w, torch.Tensor) else np.asarray(best_w)
+    out["whole__loss"] = losses(ev, field_w)
+    patch_index = slv.n_patch // 2 - 1
+    field_p = np.arange(-150, 150, 30)
+    best_p = slv.initialize_guess_from_patch(ev, patch_index=patch_index)
+    pt = slv.patches[patch_index]
+    cropped = utils.crop_event(ev, pt.x_min, pt.x_max, pt.y_min, pt.y_max)
+    out["patch__index"] = np.array(patch_index)
+    out["patch__box"] = np.array([pt.x_min, pt.x_max, pt.y_min, pt.y_max])
+    out["patch__n_events"] = np.array(len(cropped))
+    out["patch__field"] = field_p
+    out["patch__best"] = best_p.detach().cpu().numpy() if isinstance(best_p, torch.Tensor) else np.asarray(best_p)
+    out["patch__loss"] = losses(cropped, field_p)
+    logging.disable(logging.NOTSET)
+    out["n_patch"] = np.array(slv.n_patch)
+    print("global-best", out["whole__best"], "loss", out["whole__loss"].min(), "grid-best", out["patch__best"], "loss", out["patch__loss"].min())
+    save("global_best", **out)
+
+
 def gen_core():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
@@ -843,10 +895,10 @@ def gen_core():
 
 if __name__ == "__main__":
     # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search] [solver_optimize]
-    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized] [outside_sensor]   (no argument = everything)
+    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized] [outside_sensor] [global_best]   (no argument = everything)
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
                                                                     "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv", "costs_batched",
-                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized", "outside_sensor"]
+                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized", "outside_sensor", "global_best"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -875,3 +927,5 @@ if __name__ == "__main__":
         gen_warp_voxel_optimized()
     if "outside_sensor" in which:
         gen_outside_sensor()
+    if "global_best" in which:
+        gen_global_best()

@@ -275,7 +275,7 @@ def test_out_of_sensor_sources_are_dropped_not_crashing():
     ev[::10, 0] = -5.0
     ev[5::10, 1] = 1e9
     ev[7, 0] = np.nan
-    h = E.CMaxHandle((32, 40)).set_events(ev)
+    h = E.CMaxHandle((32, 40)).set_keep_outside(False).set_events(ev)  # (asked to drop: the default keeps finite off-sensor events)
     keep = np.isfinite(ev[:, 0]) & (ev[:, 0] >= 0) & (ev[:, 0] < 32) & (ev[:, 1] >= 0) & (ev[:, 1] < 40)
     assert h.n_events == int(keep.sum())
     iwe = h.iwe(np.zeros(2), "2d-translation")
@@ -312,7 +312,7 @@ def test_events_off_the_sensor_vote_like_the_reference(pad, cost, sigma):
     with pytest.raises(E._lib.CmaxError):
         h.evaluate(E.make_descriptor(cost, "dense-flow", sigma=float(sigma)), np.zeros((2,) + size, np.float32))
     # default handles drop them, as before
-    h2 = E.CMaxHandle(size, outer_padding=pad).set_events(ev, on_dropped="ignore")
+    h2 = E.CMaxHandle(size, outer_padding=pad).set_keep_outside(False).set_events(ev, on_dropped="ignore")
     assert h2.batch_info()["dropped"] == int(off.sum()) and h2.batch_info()["outside"] == 0
 
 
@@ -518,7 +518,7 @@ def test_dropped_events_are_counted_and_reported(caplog):
     ev[77, 1] = size[1] + 2.0
     ev[1234, 0] = np.nan
     with caplog.at_level(logging.WARNING):
-        h = E.CMaxHandle(size).set_events(ev)
+        h = E.CMaxHandle(size).set_keep_outside(False).set_events(ev)
     info = h.batch_info()
     assert info["dropped"] == 3 and info["packed"] == n - 3 and not info["fractional"]
     assert any("dropped 3" in r.message for r in caplog.records)
@@ -533,9 +533,20 @@ def test_dropped_events_are_counted_and_reported(caplog):
     assert h.batch_info()["dropped"] == 0
     # a solver that must not diverge from the reference silently asks for an error instead
     with pytest.raises(ValueError, match="dropped 3"):
-        E.CMaxHandle(size).set_events(ev, on_dropped="raise")
+        E.CMaxHandle(size).set_keep_outside(False).set_events(ev, on_dropped="raise")
     with pytest.raises(ValueError):
         E.CMaxHandle(size).set_events(ev, on_dropped="sometimes")
+    # THE DEFAULT (round 5) follows the reference's 2-DoF warp, which has no bounds test on the source (src/warp.py:506-515): the two
+    # finite events are kept (they vote if theta brings them in), only the NaN is dropped; a dense objective refuses such a batch
+    hk = E.CMaxHandle(size).set_events(ev, on_dropped="ignore")
+    assert hk.batch_info()["dropped"] == 1 and hk.batch_info()["outside"] == 2 and hk.batch_info()["packed"] == n - 1
+    resk, gradk = hk.evaluate(E.make_descriptor("image_variance", "2d-translation"), theta)
+    fin = np.isfinite(ev[:, 0])
+    refk = orc.objective(ev[fin], theta, "2d-translation", size, cost="image_variance", sigma=0)
+    assert abs(resk[0].item() - refk["loss"]) <= 1e-4 * abs(refk["loss"])
+    assert np.abs(gradk.cpu().numpy() - refk["grad"]).max() <= 1e-4 * np.abs(refk["grad"]).max()
+    with pytest.raises(E._lib.CmaxError, match="off the sensor"):
+        hk.evaluate(E.make_descriptor("image_variance", "dense-flow"), np.zeros((2,) + size))
 
 
 def test_prepared_call_equals_evaluate_and_follows_the_motion_buffer():

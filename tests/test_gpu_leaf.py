@@ -437,4 +437,9 @@ def test_two_dof_sources_in_the_outer_padding_vote_like_the_reference():
     assert np.abs(iwe_ref - iwe_on).max() > 0.5
     # the fused path refuses such a batch when asked to (what the solver asks for) instead of dropping the events silently
     with pytest.raises(ValueError):
-        E.CMaxHandle(size, pad).set_events(ev, on_dropped="raise")
+        E.CMaxHandle(size, pad).set_keep_outside(False).set_events(ev, on_dropped="raise")
+    # ... and BY DEFAULT (round 5) the fused 2-DoF objective keeps them like the leaf operators: same image
+    hk = E.CMaxHandle(size, pad).set_events(ev)
+    assert hk.batch_info()["outside"] == int(off) and hk.batch_info()["dropped"] == 0
+    iwe_fused = hk.iwe(theta, "2d-translation", direction="first", sigma=0).cpu().numpy()
+    np.testing.assert_allclose(iwe_fused, iwe_ref, rtol=0, atol=1e-4 * np.abs(iwe_ref).max())

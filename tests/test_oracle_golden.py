@@ -369,3 +369,26 @@ def test_events_off_the_sensor_2dof(golden, pad, cost, sigma):
     assert abs(r["loss"] - float(g[tag + "__loss"])) <= 1e-11 * abs(float(g[tag + "__loss"]))
     assert np.abs(r["grad"] - g[tag + "__grad"]).max() <= 1e-10 * np.abs(g[tag + "__grad"]).max()
     assert np.abs(r["iwes"]["iwe"] - g[tag + "__iwe"]).max() <= 1e-11
+
+
+def test_global_best_grid_losses_against_the_reference(golden):
+    """patch.initialize "global-best" / "grid-best" (src/solver/patch_contrast_base.py:164-187, 126-162): the oracle's 2-DoF objective
+    with the YAML hybrid cost on theta = candidate * t_scale reproduces the loss of every grid candidate the reference computed, and
+    the reference's own pick is the first minimum of that grid.  (A sample of the 900 + 100 candidates: the scalar oracle needs ~10 ms
+    per evaluation.)"""
+    g = golden("global_best")
+    size = tuple(int(v) for v in g["image_size"])
+    cw = {"multi_focal_normalized_gradient_magnitude": 1.0, "total_variation": 0.01}
+    rng = np.random.default_rng(0)
+    for tag, ev in (("whole", g["events"]), ("patch", orc.crop_event(g["events"], *[int(v) for v in g["patch__box"]]))):
+        field, grid = g[tag + "__field"], g[tag + "__loss"]
+        assert len(ev) == (len(g["events"]) if tag == "whole" else int(g["patch__n_events"]))
+        t_scale = ev[:, 2].max() - ev[:, 2].min()
+        best = np.unravel_index(np.argmin(grid), grid.shape)  # first minimum = the reference's strict `<`
+        np.testing.assert_array_equal([field[best[0]], field[best[1]]], g[tag + "__best"])
+        picks = {best} | {tuple(int(v) for v in rng.integers(0, len(field), 2)) for _ in range(25)}
+        for i, j in picks:
+            theta = np.array([field[i], field[j]], dtype=np.float64) * t_scale
+            ref = orc.objective(ev, theta, "2d-translation", size, cost="hybrid", sigma=1, cost_with_weight=cw,
+                                coarse_flow=theta.reshape(2, 1, 1) / t_scale, want_grad=False)
+            assert abs(ref["loss"] - grid[i, j]) <= 1e-9 * abs(grid[i, j]), (tag, i, j, ref["loss"], grid[i, j])
