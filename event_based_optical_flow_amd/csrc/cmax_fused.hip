@@ -74,6 +74,7 @@ struct EvView {
     const uint2 *ev;      // .x = row | col << 12 | bin << 24 ; .y = bits of fp32 tau = (t - tmin) / (tmax - tmin)
     const float *rx;      // fractional residual of the source coordinate (nullptr if integral)
     const float *ry;
+    const float2 *rl;     // ... its low part (rxl, ryl): residual = (double)rx + (double)rxl -- read only by warp_exact (events on a cell border)
     const double *tau64;  // BINNED handles (the packed word's top byte holds the voxel bin): normalised time in fp64, same order as `ev` --
                           // read only for the few events whose cell is decided in fp64 (warp_exact); null on un-binned handles, whose
                           // packed word carries the time's residual beyond fp32 (tau_refined)
@@ -84,6 +85,7 @@ struct WarpParams {
     int T;                     // voxel bins
     int ntc;                   // source tiles per tile row
     float d;                   // reference time as a fraction of the batch period
+    float d_lo;                // ... what fp32 could not hold of it (d64 = (double)d + (double)d_lo): read only by warp_exact
     int normalize;             // normalize_t
     int motion_f64;            // 2-DoF only: `motion` points to double[2] (cmax_objective_t::motion_dtype == CMAX_F64)
     const double *tmm;         // device (tmin, tmax)
@@ -95,6 +97,7 @@ struct WarpParams {
 // kernel class were three times the launch latency.
 struct RefArgs {
     float d[4];       // reference time as a fraction of the batch period
+    float d_lo[4];    // ... its fp32 remainder (K1's fp64 cell decisions: a reference time need not be a dyadic fraction -- "random" / float directions)
     float *img[4];    // K1: vote image to fill; K3: image to gather from (dL/dIWE or the IWE itself)
     double *stat[4];  // K1: statistics accumulators to reset (or null)
     double *raw_zero; // K1: [n_ref][kRawStride] gradient-sum lines of the 2-DoF K3 of the same evaluation to reset (or null)
@@ -175,10 +178,12 @@ struct cmax_handle_s {
     // packed, sorted events
     uint2 *evp = nullptr;  // packed events, 8 B each, 16-byte aligned base (+2 elements of padding)
     float *rx = nullptr, *ry = nullptr;
+    float2 *rl = nullptr;  // low parts of (rx, ry): written and read only for batches with fractional sources
     double *tau64 = nullptr;
     // staging SoA of the two-level sort (tile buckets before the per-tile ordering)
     uint2 *evp_alt = nullptr;
     float *rx_alt = nullptr, *ry_alt = nullptr;
+    float2 *rl_alt = nullptr;
     double *tau64_alt = nullptr;
     int64_t cap_alt = 0;
     // sort scratch
@@ -525,9 +530,15 @@ template <int MODEL, bool FRAC>
 __device__ __forceinline__ Warped warp_exact(const EvView &ev, unsigned ex, int64_t i, double tau, double period, const WarpParams &wp, double m0, double m1) {
     Warped w;
     const int ix = (int)(ex & 0xFFFu), iy = (int)((ex >> 12) & 0xFFFu);
-    const double dtd = (tau - (double)wp.d) * period;
+    const double dtd = (tau - ((double)wp.d + (double)wp.d_lo)) * period;
     const double sgn = MODEL == CMAX_MODEL_2DOF ? 1.0 : -1.0;  // x' = x + dt theta (warp.py:514)  |  x' = x - dt F (warp.py:305)
-    const double ddx = fma(sgn * dtd, m0, FRAC ? (double)ev.rx[i] : 0.0), ddy = fma(sgn * dtd, m1, FRAC ? (double)ev.ry[i] : 0.0);
+    double srx = 0.0, sry = 0.0;  // the source coordinate's residual as the reference's fp64 arithmetic sees it
+    if (FRAC) {
+        const float2 lo = ev.rl[i];
+        srx = (double)ev.rx[i] + (double)lo.x;
+        sry = (double)ev.ry[i] + (double)lo.y;
+    }
+    const double ddx = fma(sgn * dtd, m0, srx), ddy = fma(sgn * dtd, m1, sry);
     const double fxd = fmin(fmax(floor(ddx + 1e-6), -8192.0), 8192.0), fyd = fmin(fmax(floor(ddy + 1e-6), -8192.0), 8192.0);
     w.a = (float)(ddx - fxd);
     w.b = (float)(ddy - fyd);
@@ -1836,6 +1847,11 @@ static float ref_fraction(int ref_mode, double frac) {
     if (ref_mode == CMAX_REF_LAST) return 1.f;
     return (float)frac;
 }
+// ... and what fp32 lost of it (zero for the named directions and every dyadic fraction)
+static float ref_fraction_lo(int ref_mode, double frac) {
+    if (ref_mode == CMAX_REF_FIRST || ref_mode == CMAX_REF_LAST) return 0.f;
+    return (float)(frac - (double)(float)frac);
+}
 
 // 512-thread workgroups (4 events per thread) once the work list exceeds what the chip holds at once
 // (the voxel K3 then even 1024 x 2)
@@ -1999,6 +2015,7 @@ static EvView ev_view(const cmax_handle_s *h) {
     ev.ev = h->evp;
     ev.rx = h->rx;
     ev.ry = h->ry;
+    ev.rl = h->rl;
     ev.tau64 = h->n_time_bin > 0 ? h->tau64 : nullptr;
     return ev;
 }
@@ -2015,6 +2032,7 @@ static WarpParams warp_params(const cmax_handle_s *h, const float *motion, int T
     wp.T = T;
     wp.ntc = h->ntc;
     wp.d = ref_fraction(ref_mode, frac);
+    wp.d_lo = ref_fraction_lo(ref_mode, frac);
     wp.normalize = normalize;
     wp.motion_f64 = motion_f64;
     wp.tmm = h->d_tmm;
@@ -2058,6 +2076,7 @@ static int vote_images(cmax_handle_s *h, int model, const float *motion, int T, 
         if (h->n == 0 && stat_zero)  // no K1 launch on this rank: reset the accumulators explicitly
             CMAX_CHECK_HIP(hipMemsetAsync(stat_zero, 0, kStatStride * sizeof(double), s));
         ra.d[k] = ref_fraction(ref_mode[k], ref_frac[k]);
+        ra.d_lo[k] = ref_fraction_lo(ref_mode[k], ref_frac[k]);
         ra.img[k] = imgs[k];
         ra.stat[k] = stat_zero;
         if (mu_taps && !det && h->n > 0) ra.musum[k] = h->d_musum + ((int64_t)h->mu_buf * 4 + k) * kMuStride;
@@ -2445,18 +2464,20 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
         dev_free(&h->evp_alt);
         dev_free(&h->rx_alt);
         dev_free(&h->ry_alt);
+        dev_free(&h->rl_alt);
         dev_free(&h->tau64_alt);
         int rc = dev_alloc(h, &h->evp_alt, h->cap + 2);
         if (!rc) rc = dev_alloc(h, &h->rx_alt, h->cap);
         if (!rc) rc = dev_alloc(h, &h->ry_alt, h->cap);
+        if (!rc) rc = dev_alloc(h, &h->rl_alt, h->cap);
         if (!rc) rc = dev_alloc(h, &h->tau64_alt, h->cap);
         if (rc) return rc;
         h->cap_alt = h->cap;
     }
 
     const int grid = (int)div_up(n_in, (int64_t)kSortChunk);
-    const SortOut stage = {h->evp_alt, h->rx_alt, h->ry_alt, h->tau64_alt};
-    const SortOut fin = {h->evp, h->rx, h->ry, h->tau64};
+    const SortOut stage = {h->evp_alt, h->rx_alt, h->ry_alt, h->rl_alt, h->tau64_alt};
+    const SortOut fin = {h->evp, h->rx, h->ry, h->rl, h->tau64};
     unsigned long long *keys = reduce_time ? reinterpret_cast<unsigned long long *>(h->d_tmm) : nullptr;
     hipLaunchKernelGGL(k_sort_clear, dim3(div_up(ntiles + 1, 256)), dim3(256), 0, s, h->counts, h->cursor, ntiles, h->d_flags, first_flag, keys);
     hipLaunchKernelGGL((k_bucket_hist<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, h->counts, h->d_flags, keys);
@@ -2473,6 +2494,7 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
         std::swap(h->evp, h->evp_alt);
         std::swap(h->rx, h->rx_alt);
         std::swap(h->ry, h->ry_alt);
+        std::swap(h->rl, h->rl_alt);
         std::swap(h->tau64, h->tau64_alt);
     }
     static const bool run_sort = !getenv("CMAX_NO_RUN_SORT");
@@ -2487,6 +2509,7 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
             std::swap(h->evp, h->evp_alt);
             std::swap(h->rx, h->rx_alt);
             std::swap(h->ry, h->ry_alt);
+            std::swap(h->rl, h->rl_alt);
             std::swap(h->tau64, h->tau64_alt);
         }
         return 0;
@@ -2652,10 +2675,12 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->evp);
     dev_free(&h->rx);
     dev_free(&h->ry);
+    dev_free(&h->rl);
     dev_free(&h->tau64);
     dev_free(&h->evp_alt);
     dev_free(&h->rx_alt);
     dev_free(&h->ry_alt);
+    dev_free(&h->rl_alt);
     dev_free(&h->tau64_alt);
     for (int c = 0; c < CMAX_PROF_CLASSES; ++c)
         for (hipEvent_t e : h->prof_ev[c]) (void)hipEventDestroy(e);
@@ -2682,16 +2707,19 @@ int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, i
         dev_free(&h->evp);
         dev_free(&h->rx);
         dev_free(&h->ry);
+        dev_free(&h->rl);
         dev_free(&h->tau64);
         int rc = dev_alloc(h, &h->evp, n + 2);  // +2: the vector loads may touch one event past the end
         if (!rc) rc = dev_alloc(h, &h->rx, n);
         if (!rc) rc = dev_alloc(h, &h->ry, n);
+        if (!rc) rc = dev_alloc(h, &h->rl, n);
         if (!rc) rc = dev_alloc(h, &h->tau64, n);
         if (rc) return rc;
         h->cap = n;
         dev_free(&h->evp_alt);  // the staging SoA follows (sort_events)
         dev_free(&h->rx_alt);
         dev_free(&h->ry_alt);
+        dev_free(&h->rl_alt);
         dev_free(&h->tau64_alt);
         h->cap_alt = 0;
     }
@@ -2738,7 +2766,7 @@ int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream) {
     if (h->n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // re-order the packed events in place (through the staging SoA); [0] "fractional sources" stays what it was
-    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, s);
+    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->rl, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, s);
 }
 
 int cmax_set_time_slabs(cmax_handle_t h, int n_slab, cmax_stream_t stream) {
@@ -2751,7 +2779,7 @@ int cmax_set_time_slabs(cmax_handle_t h, int n_slab, cmax_stream_t stream) {
     h->slab_major = n_slab > 0;
     bump_generation_keep_counts(h);
     if (h->n == 0) return 0;
-    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, (hipStream_t)stream);
+    return sort_events(h, PackedSource{h->evp, h->rx, h->ry, h->rl, h->tau64, h->has_frac ? 1 : 0}, h->n, false, 1, (hipStream_t)stream);
 }
 
 int cmax_iwe(cmax_handle_t h, int model, const float *motion, int T, int ref_mode, double ref_frac, int normalize_t,
@@ -2823,7 +2851,10 @@ static int publish_windows(cmax_handle_s *h, const cmax_objective_t *d, const fl
     ra.win = h->d_win;
     ra.shifts = h->d_shifts;
     ra.windows_only = 1;
-    for (int k = 0; k < d->n_ref; ++k) ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+    for (int k = 0; k < d->n_ref; ++k) {
+        ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.d_lo[k] = ref_fraction_lo(d->ref_mode[k], d->ref_frac[k]);
+    }
     const EvView ev = ev_view(h);
     const WarpParams wp = warp_params(h, motion, d->T, d->ref_mode[0], d->ref_frac[0], d->normalize_t, d->motion_dtype == CMAX_F64);
     switch (d->model) {
@@ -3120,6 +3151,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
                      h->win_nref == d->n_ref && h->win_T == d->T && h->win_normalize == d->normalize_t;
     for (int k = 0; k < d->n_ref; ++k) {
         ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.d_lo[k] = ref_fraction_lo(d->ref_mode[k], d->ref_frac[k]);
         ra.img[k] = (fold == kFoldNone || fold == kFoldScale) ? h->G + k * npix : const_cast<float *>(h->last_iwe[k]);
         ra.zero[k] = (deferred || stats_inside) ? ia.zero[k] : nullptr;
         same_vote = same_vote && h->win_d[k] == ra.d[k];
@@ -3269,6 +3301,7 @@ static int objective_eval_tan2(cmax_handle_t h, const cmax_objective_t *d, const
     for (int k = 0; k < nr; ++k) {
         if (!((h->tan_zero_mask[h->tan_cur] >> k) & 1u)) CMAX_CHECK_HIP(hipMemsetAsync(cur + k * tstride, 0, (size_t)tstride * sizeof(float), s));
         ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.d_lo[k] = ref_fraction_lo(d->ref_mode[k], d->ref_frac[k]);
         ra.img[k] = cur + k * tstride;
     }
     const unsigned used = (1u << nr) - 1u;
@@ -3468,6 +3501,7 @@ int cmax_objective_batch(cmax_handle_t h, const cmax_objective_t *d, const void 
     ra.z_motion = (int)mfloats;
     for (int k = 0; k < nr; ++k) {
         ra.d[k] = ref_fraction(d->ref_mode[k], d->ref_frac[k]);
+        ra.d_lo[k] = ref_fraction_lo(d->ref_mode[k], d->ref_frac[k]);
         ra.img[k] = cur + k * npix;
         ra.stat[k] = h->braw + (int64_t)k * kRawStride;  // K1's first workgroup of every (candidate, reference time) resets its lines
         ra.zero[k] = nxt + k * npix;                      // K3 clears the other buffer's image of the same (candidate, reference time)

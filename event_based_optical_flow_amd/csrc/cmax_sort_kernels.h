@@ -76,6 +76,8 @@ __device__ __forceinline__ double tau_refined(uint2 e) {
 struct SortItem {
     int ix, iy;     // source pixel; ix < 0: not on the sensor (dropped)
     float rx, ry;   // fractional parts of the source coordinates
+    float rxl, ryl; // ... and what fp32 could not hold of them: residual = (double)rx + (double)rxl to 2^-48 (round 5: the cells of events
+                    // on a cell border are decided from the source coordinate the reference's fp64 arithmetic sees, warp_exact)
     double tn;      // time normalised to the batch
     bool frac;
     bool outside;   // kept although off the sensor (RawSource::keep_outside): (ix, iy) is the NEAREST sensor pixel, (rx, ry) the rest
@@ -117,8 +119,11 @@ struct RawSource {
         const T x = ev[4 * i + 0], y = ev[4 * i + 1];
         SortItem it = classify(x, y);
         if (it.ix >= 0) {
-            it.rx = (float)(x - (T)it.ix);  // (on the sensor: ix = floor(x))
-            it.ry = (float)(y - (T)it.iy);
+            const double rxd = (double)x - (double)it.ix, ryd = (double)y - (double)it.iy;  // exact (on the sensor: ix = floor(x))
+            it.rx = (float)rxd;
+            it.ry = (float)ryd;
+            it.rxl = (float)(rxd - (double)it.rx);
+            it.ryl = (float)(ryd - (double)it.ry);
             double tmin = tmm[0], tmax = tmm[1];
             if (keyed) {
                 const unsigned long long *k = reinterpret_cast<const unsigned long long *>(tmm);
@@ -136,6 +141,7 @@ struct RawSource {
 struct PackedSource {
     const uint2 *evp;
     const float *rx, *ry;  // written only for batches with fractional source coordinates (has_frac)
+    const float2 *rl;      // (rxl, ryl), likewise
     const double *tau64;
     int has_frac;
     __device__ __forceinline__ bool reduces_time() const { return false; }
@@ -153,6 +159,9 @@ struct PackedSource {
         SortItem it = pixel(i);
         it.rx = has_frac ? rx[i] : 0.f;
         it.ry = has_frac ? ry[i] : 0.f;
+        const float2 lo = has_frac ? rl[i] : make_float2(0.f, 0.f);
+        it.rxl = lo.x;
+        it.ryl = lo.y;
         it.tn = tau64[i];
         return it;
     }
@@ -161,6 +170,7 @@ struct PackedSource {
 struct SortOut {
     uint2 *evp;
     float *rx, *ry;
+    float2 *rl;  // (rxl, ryl): low parts of the fractional residuals (SortItem)
     double *tau64;
 };
 
@@ -300,6 +310,7 @@ k_bucket_scatter(SRC src, int64_t n, int ntc, int ntiles, int T, const int *__re
         if (frac) {
             out.rx[pos] = it.rx;
             out.ry[pos] = it.ry;
+            out.rl[pos] = make_float2(it.rxl, it.ryl);
         }
         out.tau64[pos] = it.tn;
     }
@@ -385,12 +396,15 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
         const bool two = i0 + 1 < e;
         const uint2 ea = in.evp[i0], eb = two ? in.evp[i0 + 1] : make_uint2(0u, 0u);
         float rxa = 0.f, rya = 0.f, rxb = 0.f, ryb = 0.f;
+        float2 rla = make_float2(0.f, 0.f), rlb = make_float2(0.f, 0.f);
         if (frac) {
             rxa = in.rx[i0];
             rya = in.ry[i0];
+            rla = in.rl[i0];
             if (two) {
                 rxb = in.rx[i0 + 1];
                 ryb = in.ry[i0 + 1];
+                rlb = in.rl[i0 + 1];
             }
         }
         const double ta = in.tau64[i0], tb = two ? in.tau64[i0 + 1] : 0.0;
@@ -399,6 +413,7 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
         if (frac) {
             out.rx[pa] = rxa;
             out.ry[pa] = rya;
+            out.rl[pa] = rla;
         }
         out.tau64[pa] = ta;
         if (two) {
@@ -407,6 +422,7 @@ k_tile_sort(int ntiles, int T, const int *__restrict__ tile_off, SortOut in, Sor
             if (frac) {
                 out.rx[pb] = rxb;
                 out.ry[pb] = ryb;
+                out.rl[pb] = rlb;
             }
             out.tau64[pb] = tb;
         }
@@ -459,6 +475,7 @@ __global__ void __launch_bounds__(256) k_slab_regroup(const int *__restrict__ ol
         if (frac) {
             out.rx[d + i] = in.rx[b + i];
             out.ry[d + i] = in.ry[b + i];
+            out.rl[d + i] = in.rl[b + i];
         }
     }
 }
@@ -515,6 +532,7 @@ __global__ void __launch_bounds__(256) k_run_time_sort(SortOut in, SortOut out, 
         if (frac) {
             out.rx[pos] = in.rx[i];
             out.ry[pos] = in.ry[i];
+            out.rl[pos] = in.rl[i];
         }
         out.tau64[pos] = in.tau64[i];
     }

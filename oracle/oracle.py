@@ -423,8 +423,11 @@ def required_keys(cost, cost_with_weight=None):
 
 def objective(events, motion, motion_model, image_size, cost="image_variance", sigma=0, outer_padding=0,
               iwe_method="bilinear_vote", omit_boundary=True, direction="minimize", cost_with_weight=None,
-              coarse_flow=None, normalize_t=True, want_grad=True):
+              coarse_flow=None, normalize_t=True, want_grad=True, warp_direction="first"):
     """One evaluation of the reference objective; returns dict(loss, grad, iwes, image_grads, grad_flow).
+
+    warp_direction: reference time of the "iwe" key -- "first" in get_arg_for_cost (patch_contrast_base.py:310-312); any direction
+    Warp.calculate_reftime takes (src/warp.py:201-233: names or a float) for callers of the leaf API that warp elsewhere.
 
     `motion` is theta[2] / flow[2,H,W] / voxel[T,2,H,W] (already in pixel per normalised time, i.e.
     what `calculate_cost` receives).  `coarse_flow` is the patch-flow array handed to
@@ -439,7 +442,7 @@ def objective(events, motion, motion_model, image_size, cost="image_variance", s
     if "iwe" in need or "backward_iwe" in need:
         need = [k for k in need if k not in ("iwe", "backward_iwe")] + ["iwe"]
     for key in need:
-        warped, aux = warp_event(ev, motion, motion_model, _KEY_DIRECTION[key], image_size, normalize_t)
+        warped, aux = warp_event(ev, motion, motion_model, warp_direction if key == "iwe" else _KEY_DIRECTION[key], image_size, normalize_t)
         img = create_iwe(warped, image_size, outer_padding, iwe_method, sigma)
         ctx[key] = (warped, aux)
         iwes[key] = img

@@ -354,3 +354,27 @@ def test_bench_batch8_row_on_cfg2_stream():
         assert abs(r1[0].item() - results[z, 0]) <= 1e-6 * abs(results[z, 0]) and rel_max(g1.cpu().numpy(), grads[z]) <= 1e-5
     print(f"[fullsize] cfg2_batch8: worst rel err over 8 candidates loss {worst[0]:.2e} grad {worst[1]:.2e}")
     h.close()
+
+
+@pytest.mark.parametrize("model", ["2d-translation", "dense-flow"])
+def test_fractional_sources_and_a_non_dyadic_reference_time_at_the_plain_gate(model):
+    """Round 5.  The leaf API accepts what the reference's pipeline never produces: source coordinates with fractional
+    parts (rectified events before the cast of src/utils/event_utils.py:110-115) and a reference time anywhere in the batch
+    (Warp.calculate_reftime, src/warp.py:216-218).  1M such events, reference time at 1/3 of the batch: every gradient entry at 1e-4 --
+    the events on a cell border are decided from the fp64 source residual (rx + rx_lo) and the fp64 reference time (d + d_lo)."""
+    size, n = (260, 346), 1_000_000
+    rng = np.random.default_rng(21)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=21)
+    ev[:, 0] = np.minimum(ev[:, 0] + rng.uniform(0, 1, n), size[0] - 1e-3)
+    ev[:, 1] = np.minimum(ev[:, 1] + rng.uniform(0, 1, n), size[1] - 1e-3)
+    direction = 1.0 / 3.0
+    motion = np.array([12.3, -7.7]) if model == "2d-translation" else f32(E.utils.generate_smooth_flow(size, 20, seed=1021))
+    h = E.CMaxHandle(size).set_events(ev)
+    assert h.batch_info()["fractional"]
+    desc = E.make_descriptor("image_variance", model, warp_direction=direction)
+    ref = orc.objective(ev, motion, model, size, cost="image_variance", sigma=0, warp_direction=direction)
+    _, n_amb = ambiguity_bound(ev, motion, model, size, raw_image_grad(ref, 0), direction=direction)
+    for rep in range(2):
+        res, grad = h.evaluate(desc, motion)
+        check(f"{model} 1M fractional sources, reference time 1/3 #{rep}", h, res, grad, ref, None, n_amb)
+    h.close()

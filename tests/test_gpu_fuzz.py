@@ -41,7 +41,12 @@ def draw_case(seed):
         else:
             T = int(rng.choice([1, 3, 10]))
             motion = np.stack([f0 * (1.0 + 0.05 * k) for k in range(T)])
-    return dict(H=H, W=W, pad=pad, n=n, model=model, cost=cost, sigma=sigma, ev=ev, motion=motion, T=T, frac=frac)
+    # (drawn last, so that the draws above are those of rounds 1-4) the reference time: "first" as get_arg_for_cost warps, or -- costs
+    # with ONE reference time -- a fraction of the batch that fp32 cannot hold (Warp.calculate_reftime takes any float, src/warp.py:216-218)
+    direction = "first"
+    if not cost.startswith("multi_focal") and rng.random() < 0.35:
+        direction = float(rng.choice([0.3, 0.7321, 1.0 / 3.0, -0.25, 1.6]))
+    return dict(H=H, W=W, pad=pad, n=n, model=model, cost=cost, sigma=sigma, ev=ev, motion=motion, T=T, frac=frac, direction=direction)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CMAX_FUZZ_SEEDS", "54"))))
@@ -50,9 +55,10 @@ def test_random_configuration_against_oracle(seed):
     size = (c["H"], c["W"])
     if c["model"] != "2d-translation":  # the flow as the device holds it: rounded to fp32 (a 2-DoF theta crosses the ABI in fp64)
         c["motion"] = np.asarray(c["motion"], dtype=np.float32).astype(np.float64)
-    ref = orc.objective(c["ev"], c["motion"], c["model"], size, cost=c["cost"], sigma=c["sigma"], outer_padding=c["pad"])
+    ref = orc.objective(c["ev"], c["motion"], c["model"], size, cost=c["cost"], sigma=c["sigma"], outer_padding=c["pad"],
+                        warp_direction=c["direction"])
     h = E.CMaxHandle(size, c["pad"]).set_events(c["ev"], time_bin=c["T"])
-    obj = E.ContrastObjective(h, c["model"], cost=c["cost"], sigma=c["sigma"])
+    obj = E.ContrastObjective(h, c["model"], cost=c["cost"], sigma=c["sigma"], warp_direction=c["direction"])
     m = torch.as_tensor(np.ascontiguousarray(c["motion"]), dtype=torch.float64, device="cuda").requires_grad_()
     loss = obj(m)
     (g,) = torch.autograd.grad(loss, m)
@@ -61,35 +67,22 @@ def test_random_configuration_against_oracle(seed):
     if not np.isfinite(ref["loss"]):  # degenerate draw (constant image under a normalised cost): both sides agree it is not finite
         assert not np.isfinite(loss.item()), info
         return
-    # floor(x' + 1e-6) is discontinuous: an event whose warped coordinate lies within fp32 rounding of a cell border
-    # votes into the neighbouring cell in fp32 (the reference in fp32 would too).  Such draws are compared at the
-    # size of one event's contribution instead of the gate.
-    tol, n_border = 1e-4, 0
-    for direction in ("first", "middle", "last"):
-        w, _ = orc.warp_event(c["ev"], c["motion"], c["model"], direction, size)
-        frac = np.mod(w[:, :2] + 1e-6, 1.0)
-        if np.isfinite(frac).all():
-            n_border += int((np.minimum(frac, 1.0 - frac) < 3e-5).sum())
-    # (events on a cell border are re-warped in fp64 -- 2-DoF: round 3, with its theta crossing the ABI in fp64; dense / voxel: round 4,
-    # against the oracle on the fp32-rounded flow -- so the plain gate holds for integral source coordinates; fractional ones are
-    # stored as fp32 residuals, which can still flip a cell)
-    if n_border and c["frac"]:
-        tol = 2e-2
+    # floor(x' + 1e-6) is discontinuous: an event whose warped coordinate lies within fp32 rounding of a cell border votes into the
+    # neighbouring cell in any fp32 evaluation (the reference's own fp32 path too) and takes its derivative from the wrong side of the
+    # kink.  K1 decides those cells in fp64 -- from the caller's fp64 theta / the fp32 flow the device holds (rounds 3-4), and since
+    # round 5 from the SOURCE COORDINATE and the REFERENCE TIME as the reference's fp64 arithmetic sees them (fractional sources keep the
+    # low part of their residual, a reference time that is no dyadic fraction crosses as a pair of floats): the PLAIN gate for every draw.
+    tol = 1e-4
     assert abs(loss.item() - ref["loss"]) <= tol * max(abs(ref["loss"]), 1e-12), (info, loss.item(), ref["loss"])
     gmax = np.abs(ref["grad"]).max()
     if gmax > 0:
         err = np.abs(g - ref["grad"])
-        if n_border and c["frac"] and c["model"] != "2d-translation":
-            # per-pixel gradients: an event ON a cell border leaves the image unchanged but takes its derivative from the
-            # neighbouring cell -- its own flow-gradient pixel (x, y channel, per reference time) differs by one event's term
-            assert (err > 1e-4 * gmax).sum() <= 6 * n_border and err.max() <= gmax, (info, n_border, err.max(), gmax)
-        else:
-            assert err.max() <= tol * gmax, (info, tol, err.max(), gmax)
+        assert err.max() <= tol * gmax, (info, c["frac"], c["direction"], err.max(), gmax)
     else:
         assert np.abs(g).max() == 0, info
     # the same evaluation delivered to the host (cmax_objective_host; 2-DoF variance: the pinned-memory finishing kernel) and,
     # where the objective has one, in its raw form: identical to the device-result form up to the atomics' summation order
-    desc = E.make_descriptor(c["cost"], c["model"], sigma=float(c["sigma"]), time_bin=c["T"])
+    desc = E.make_descriptor(c["cost"], c["model"], sigma=float(c["sigma"]), time_bin=c["T"], warp_direction=c["direction"])
     res_h, grad_h = h.evaluate_host(desc, m.detach())
     scale = max(abs(loss.item()), 1e-12)
     assert abs(res_h[0] - loss.item()) <= 2e-6 * scale, (info, res_h[0], loss.item())

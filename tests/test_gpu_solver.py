@@ -696,7 +696,12 @@ def test_patch_objective_keeps_large_motions_in_time_slabs():
         x = (np.array([[1.0], [-0.66]]) * scale_px * (1.0 + 0.05 * rng.uniform(-1, 1, (2, 4)))).reshape(-1) / t_scale
         loss, grad = obj.value_and_grad_numpy(x)
         assert h.time_slabs == want_slabs, (scale_px, h.time_slabs)
-        ref_loss, ref_grad = orc.solver_objective(ev, x, size, pis, ps, ps, (2, 5), cost="image_variance", sigma=0)
+        # the oracle on the flow THE DEVICE HOLDS (as in tests/test_gpu_fullsize.py): the plan interpolates in fp64 and rounds the
+        # displacement field to fp32 once; at 150 px that rounding (9e-6 px) decides the cell of a few dozen events on a cell border
+        pad = patch_pad(ps, ps, (2, 5))
+        dense = np.asarray(orc.patch_to_dense(x.reshape(2, 2, 2), size, ps, pad) * t_scale, dtype=np.float32).astype(np.float64)
+        ref = orc.objective(ev, dense, "dense-flow", size, cost="image_variance", sigma=0)
+        ref_loss, ref_grad = ref["loss"], orc.patch_to_dense_adj(ref["grad"] * t_scale, pis, ps, pad).reshape(-1)
         e_l, e_g = abs(loss - ref_loss) / abs(ref_loss), rel_max(grad, ref_grad)
         print(f"[solver] patch objective at {scale_px:.0f} px: {h.time_slabs} slabs, rel err loss {e_l:.2e} grad {e_g:.2e}")
         assert e_l <= TOL and e_g <= TOL

@@ -26,14 +26,18 @@ if no_slabs:
 rows = []
 for v in ((12.0, -8.0), (140.0, -90.0)):
     rng = np.random.default_rng(7)
-    n_dots = 4000
-    tau = np.sort(rng.uniform(0, 1, N))
-    dot = rng.integers(0, n_dots, N)
+    # dots spread over the sensor + the margin they cross during the batch; as many raw events as it takes for N of them to fall on
+    # the sensor (both scenes are timed on N events)
+    area = (H + 2 * abs(v[0])) * (W + 2 * abs(v[1])) / (H * W)
+    n_raw, n_dots = int(N * area * 1.15), int(4000 * area)
+    tau = np.sort(rng.uniform(0, 1, n_raw))
+    dot = rng.integers(0, n_dots, n_raw)
     cx, cy = rng.uniform(-abs(v[0]), H + abs(v[0]), n_dots), rng.uniform(-abs(v[1]), W + abs(v[1]), n_dots)
-    x = np.round(cx[dot] + tau * v[0] + rng.normal(0, 0.4, N))
-    y = np.round(cy[dot] + tau * v[1] + rng.normal(0, 0.4, N))
-    keep = (x >= 0) & (x < H) & (y >= 0) & (y < W)
-    ev = np.stack([x, y, tau * t_scale, rng.integers(0, 2, N).astype(float)], 1)[keep]
+    x = np.round(cx[dot] + tau * v[0] + rng.normal(0, 0.4, n_raw))
+    y = np.round(cy[dot] + tau * v[1] + rng.normal(0, 0.4, n_raw))
+    keep = np.nonzero((x >= 0) & (x < H) & (y >= 0) & (y < W))[0]
+    keep = np.sort(rng.choice(keep, N, replace=False)) if len(keep) > N else keep
+    ev = np.stack([x, y, tau * t_scale, rng.integers(0, 2, n_raw).astype(float)], 1)[keep]
     slv_cfg = {"method": "pyramidal_patch_contrast_maximization", "time_aware": False,
                "patch": {"initialize": "global-best", "scale": 3, "crop_height": 256, "crop_width": 336, "filter_type": "bilinear", "search_grid": 0},
                "motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"],
