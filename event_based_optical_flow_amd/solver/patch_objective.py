@@ -18,6 +18,28 @@ from .. import functional as F
 from ..cmax import CMaxHandle, ContrastObjective
 
 
+class _SlicedFusedFn(torch.autograd.Function):
+    """One fused term on a TIME-SLICED batch with torch.distributed collectives -- the fall-back of cmax_patch_plan_* under a
+    communicator (e.g. gloo, or RCCL refused): this rank's votes -> all-reduce of the images (C1) -> contrast and the gradient of THIS
+    RANK'S events.  backward hands autograd that SHARE of dL/dflow; PatchFlowObjective reduces the shares after the adjoint of the
+    patch interpolation -- 2 n_patch numbers cross the fabric instead of the flow gradient, like in the library's own plan."""
+
+    @staticmethod
+    def forward(ctx, motion, sliced, desc):
+        local = sliced.local
+        images = local.objective_vote(desc, motion)
+        sliced._all_reduce(images)
+        result, grad = local.objective_finish(desc, motion, images, want_grad=motion.requires_grad)
+        ctx.grad, ctx.mdtype = grad, motion.dtype
+        return result[0].to(motion.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.grad is None:
+            return None, None, None
+        return ctx.grad.to(ctx.mdtype) * gout.to(ctx.mdtype), None, None
+
+
 def patch_pad(patch_size, sliding_window, patch_shift=(0, 0)) -> Tuple[int, int]:
     """pad_h, pad_w of the reference's interpolation (patch_contrast_base.py:470-479)."""
     return tuple(int(patch_size[k] / 2 // sliding_window[k]) + patch_shift[k] // sliding_window[k] + 1 for k in range(2))
@@ -27,7 +49,10 @@ class PatchFlowObjective:
     def __init__(self, handle: CMaxHandle, t_scale: float, patch_image_size, patch_size, sliding_window,
                  patch_shift=(0, 0), cost: str = "hybrid", cost_with_weight: Optional[Dict[str, Union[float, str]]] = None,
                  blur_sigma: float = 1.0, time_aware: bool = False, time_bin: int = 10,
-                 flow_interpolation: str = "burgers", t0_flow_location: str = "middle", filter_type: str = "bilinear"):
+                 flow_interpolation: str = "burgers", t0_flow_location: str = "middle", filter_type: str = "bilinear", sliced=None):
+        """sliced: a distributed.TimeSlicedObjective around `handle` when the batch is time-sliced over ranks.  With the library's own
+        communicator on the handle (RCCL) the native plan evaluates the whole batch (cmax_patch_plan_* exchange images + 2 n_patch
+        numbers); otherwise -- torch.distributed collectives -- the autograd-chained path below does the same two exchanges."""
         if filter_type != "bilinear":
             raise NotImplementedError("only the bilinear patch filter (the shipped configs) is built")
         self.handle = handle
@@ -46,7 +71,9 @@ class PatchFlowObjective:
         self.device = handle.device  # read by scipy_autograd.TorchWrapper
         self.auto_slabs = True  # ensure_time_slabs: time-slab order of the batch follows the motion's size
         self._plan = None
-        self._build_native_plan()
+        self.sliced = sliced if (sliced is not None and sliced.world_size > 1 and not sliced.collectives.startswith("in-library")) else None
+        if self.sliced is None:
+            self._build_native_plan()
 
     # -- one-call native path (cmax_patch_plan_*, csrc/cmax_solver.hip) ---------------------------------
     def _build_native_plan(self):
@@ -167,7 +194,7 @@ class PatchFlowObjective:
         chain (cmax_voxel_construct_tan / _adj_tan).  The total-variation term is piecewise linear: zero Hessian
         almost everywhere (a difference quotient of the whole objective would push its kinks into the curvature); with an
         "inv" weight it still contributes its rank-one part phi'' <grad TV, v> grad TV."""
-        return self.contrast.has_exact_hvp
+        return self.contrast.has_exact_hvp and self.sliced is None  # (fall-back across ranks: difference quotient of the gradient)
 
     def _smooth_grad(self, x: torch.Tensor) -> torch.Tensor:
         """Gradient of the contrast terms (everything except total_variation) w.r.t. x."""
@@ -227,4 +254,25 @@ class PatchFlowObjective:
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         x = x.to(self.handle.device)
         self.ensure_time_slabs(x)
+        if self.sliced is not None:
+            return self._call_sliced(x)
         return self.contrast(self.dense_flow(x), x.reshape((2,) + self.patch_image_size))
+
+    def _call_sliced(self, x: torch.Tensor) -> torch.Tensor:
+        """The objective on a time-sliced batch with torch.distributed collectives: identical loss and gradient on every rank."""
+        from ..costs.hybrid import combine
+
+        xs = x.clone()  # the tensor the EVENT terms depend on: its gradient is this rank's share -> summed over the ranks
+        if xs.requires_grad:
+            xs.register_hook(lambda g: self.sliced._all_reduce(g.contiguous().clone()))
+        dense = self.dense_flow(xs)
+        loss = 0.0
+        for name, weight, desc in self.contrast.terms:
+            if desc is None:  # total variation of the patch grid: replicated on every rank, not a share
+                value = F.total_variation(x.reshape((2,) + self.patch_image_size), self.contrast.omit_boundary)
+                if self.contrast.direction != "minimize":
+                    value = -value
+            else:
+                value = _SlicedFusedFn.apply(dense, self.sliced, desc)
+            loss = loss + combine(weight, value)
+        return loss

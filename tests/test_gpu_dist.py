@@ -258,6 +258,37 @@ def test_eight_ranks_sharing_one_gpu():
         assert c["loss_spread_over_ranks"] <= 1e-12 * abs(c["loss_single"])  # evaluated redundantly per rank: fp64 summation order
 
 
+def test_patch_objective_two_ranks_with_unequal_and_empty_slices():
+    """the solver's objective across ranks when the library's own communicator is not available -- two processes on one
+    GPU, gloo, slices of 70 % / 30 % and 100 % / 0 % of the batch.  Images are exchanged at full size (C1), the gradient as 2 n_patch
+    numbers behind the adjoint of the patch interpolation; every rank ends with the same loss, gradient and (difference-quotient)
+    Hessian-vector product, equal to the single-handle native plan's.  tests/_dist_worker.py (CMAX_DIST_CASE=patch) is the rank program."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "2"
+    env["CMAX_DIST_CASE"] = "patch"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["world"] == 2 and len(out["cases"]) == 4
+    for c in out["cases"]:
+        print(f"[2 ranks, patch objective] {c['slices']} {c['cost']} slice {c['slice']}: loss {c['loss']:.9g} vs {c['loss_single']:.9g}, "
+              f"grad diff {c['grad_rel_diff']:.2e}, hvp (difference quotient vs exact) {c['hvp_rel_diff']:.2e}, spread {c['spread_over_ranks']:.1e}")
+        assert abs(c["loss"] - c["loss_single"]) <= 2e-6 * abs(c["loss_single"])
+        assert c["grad_rel_diff"] <= 2e-5
+        assert c["hvp_rel_diff"] <= 5e-2  # a difference quotient of fp32 gradients against the exact product
+        assert c["spread_over_ranks"] <= 1e-9 * max(1.0, abs(c["loss_single"]))
+
+
 @pytest.mark.parametrize("cost,sigma", [("image_variance", 0.0), ("gradient_magnitude", 1.0)])
 def test_gradient_exchange_in_row_bands(world1_nccl, cost, sigma):
     """cmax_comm_set_c2_bands: the owned dense K3 launched in bands of tile rows, every band's gradient rows all-reduced on
