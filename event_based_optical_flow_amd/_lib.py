@@ -141,6 +141,7 @@ SIGNATURES = {
     "cmax_handle_info": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "cmax_debug_launch_floor": (c_int, [c_vp, c_int, c_vp]),
     "cmax_debug_timeline": (c_int, [c_vp]),
+    "cmax_debug_packed_events": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_int), c_vp]),
     "cmax_batch_info": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cmax_work_list_info": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cmax_sizeof_patch_objective": (c_int, []),

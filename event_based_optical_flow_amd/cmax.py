@@ -151,6 +151,17 @@ class CMaxHandle:
         check(self._lib.cmax_batch_outside(self._h, ctypes.byref(out)))
         return {"packed": n.value, "dropped": d.value, "fractional": bool(f.value), "owned_groups": bool(o.value), "outside": out.value}
 
+    def packed_events(self):
+        """(packed [n, 2] int64 on the host: word 0 = row | col << 12 | top byte << 24, word 1 = bits of the fp32 normalised time;
+        group starts [n_groups + 1]) of the current batch in its sorted order (cmax_debug_packed_events) -- for tests of the order."""
+        n = self.n_events
+        ev = torch.empty((max(n, 1), 2), dtype=torch.int32, device=self.device)
+        ng = ctypes.c_int(0)
+        tiles = ((self.image_size[0] + 15) // 16) * ((self.image_size[1] + 15) // 16)
+        gs = torch.empty(tiles * 256 + 1, dtype=torch.int32, device=self.device)
+        check(self._lib.cmax_debug_packed_events(self._h, ev.data_ptr(), gs.data_ptr(), ctypes.byref(ng), F._stream()))
+        return (ev[:n].cpu().numpy().astype(np.int64) & 0xFFFFFFFF), gs[: ng.value + 1].cpu().numpy()
+
     def work_list_info(self) -> Dict[str, int]:
         """{"segments", "segment_events", "small_accumulators"} of the work list the last set_events / set_time_bins cut
         (cmax_work_list_info): one workgroup of the event kernels per segment; segment_events is 2040 or 4088 (big segments)."""

@@ -4186,6 +4186,16 @@ int cmax_debug_timeline(void *device_buffer) {
 #endif
 }
 
+int cmax_debug_packed_events(cmax_handle_t h, void *events_out, int *group_start_out, int *n_groups_host, cmax_stream_t stream) {
+    CMAX_REQUIRE(h != nullptr && events_out != nullptr, "debug_packed_events");
+    const int ngroups = h->ntr * h->ntc * (h->n_time_bin > 0 ? h->n_time_bin : 1);
+    if (n_groups_host) *n_groups_host = ngroups;
+    if (h->n > 0) CMAX_CHECK_HIP(hipMemcpyAsync(events_out, h->evp, (size_t)h->n * sizeof(uint2), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (group_start_out)
+        CMAX_CHECK_HIP(hipMemcpyAsync(group_start_out, h->d_tile_start, (size_t)(ngroups + 1) * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 // Launch floor of the current work list: `pairs` times two dependent EMPTY launches with the grids of K1 and K3 of a single-reference
 // objective on this batch (the launch structure of the headline evaluation).  bench.py brackets it with events: what the evaluation
 // would cost if its kernels did nothing (profiles/r03_launch_floor.txt measured the same with tools/microbench_launch.hip).

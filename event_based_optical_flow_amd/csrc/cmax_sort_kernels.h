@@ -489,46 +489,113 @@ __global__ void __launch_bounds__(256) k_slab_regroup(const int *__restrict__ ol
 constexpr int kRunSortMax = 192;
 constexpr int kRunSortChunk = 1024;            // events per workgroup (256 threads x 4)
 constexpr int kRunSortHalo = kRunSortMax + 8;  // neighbours staged on either side: a run is followed at most kRunSortMax + 1 events far
-// The (pixel key, time bits) of a chunk and its halos are staged in LDS once; finding the run of an event and ranking the event
-// inside it are LDS reads (round 3: with global loads the kernel cost O(run length) memory round trips per event -- 37 us per 1M
-// events at 11 events per pixel, 6.6 ms for 64M events at 69).
+constexpr int kRunSortSpan = kRunSortChunk + 2 * kRunSortHalo;  // staged positions
+constexpr int kRunSortPer = (kRunSortSpan + 255) / 256;          // ... per thread (consecutive) in the two boundary scans
+// The (pixel key, time bits) of a chunk and its halos are staged in LDS once (round 3: with global loads the kernel cost O(run
+// length) memory round trips per event).  Round 5: the RUN of an event -- first and one-past-last staged position of its pixel --
+// comes from two scans over the staged keys (the last run head at or before a position, the first one behind it) instead of each
+// thread walking outwards from its event with dependent LDS reads (~140 serial reads per event at 69 events per pixel: 64M events
+// 4.45 ms, a quarter of a TB/s), and the ranking loop reads four neighbours per step, all independent: the kernel is then bound by
+// LDS throughput and the 32 B per event it moves (profiles/r05_set_events.txt).
 __global__ void __launch_bounds__(256) k_run_time_sort(SortOut in, SortOut out, const int *__restrict__ total, const int *__restrict__ flags) {
-    __shared__ uint32_t s_key[kRunSortChunk + 2 * kRunSortHalo];
-    __shared__ uint32_t s_tau[kRunSortChunk + 2 * kRunSortHalo];
+    __shared__ uint32_t s_key[kRunSortSpan + 1];   // [q + 1]: s_key[0] is the position in front of the staged range
+    __shared__ uint32_t s_tau[kRunSortSpan];
+    __shared__ short s_rs[kRunSortSpan], s_re[kRunSortSpan];  // run start / one past the run's end (staged positions); -1 / span + 1: out of sight
+    __shared__ int s_wave[2][256 / kWave];
     const int64_t n = *total;  // events that survived the packing (the grid covers the batch as it came in)
     const int64_t base = (int64_t)blockIdx.x * kRunSortChunk;
     if (base >= n) return;
     const bool frac = flags[0] != 0;
-    const int64_t lo = base - kRunSortHalo;  // global index of s_key[0]
-    for (int q = threadIdx.x; q < kRunSortChunk + 2 * kRunSortHalo; q += 256) {
-        const int64_t g = lo + q;
-        uint2 e = make_uint2(0xFFFFFFFFu, 0u);  // outside the batch: a key no event has (the top byte is masked off real keys)
-        if (g >= 0 && g < n) e = in.evp[g];
-        s_key[q] = g >= 0 && g < n ? (e.x & 0x00FFFFFFu) : 0xFFFFFFFFu;
-        s_tau[q] = e.y;
+    const int64_t lo = base - kRunSortHalo;  // global index of staged position 0
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    // keys outside the batch: two different values no event has (the top byte is masked off real keys), so that the batch's first and
+    // last run end where the batch ends; the position in front of the staged range: unknown -> a third value, handled as "out of sight"
+    for (int q = t; q < kRunSortSpan + 1; q += 256) {
+        const int64_t g = lo + q - 1;
+        uint32_t key = g < 0 ? 0xFFFFFFFEu : 0xFFFFFFFFu;
+        if (g >= 0 && g < n) {
+            const uint2 e = in.evp[g];
+            key = e.x & 0x00FFFFFFu;
+            if (q >= 1) s_tau[q - 1] = e.y;
+        } else if (q >= 1) {
+            s_tau[q - 1] = 0u;
+        }
+        s_key[q] = key;
+    }
+    __syncthreads();
+    // head[q]: position q starts a run (its key differs from the one in front of it).  Position 0's predecessor is staged too
+    // (s_key[0]) unless it lies in front of the batch.
+    auto head = [&](int q) { return s_key[q + 1] != s_key[q]; };
+    const int q0 = t * kRunSortPer, q1 = min(q0 + kRunSortPer, kRunSortSpan);
+    // forward: last head at or before q (-1: none staged)
+    int last = -1;
+    for (int q = q0; q < q1; ++q) last = head(q) ? q : last;
+    int incl = last;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl = max(incl, v);
+    }
+    if (lane == kWave - 1) s_wave[0][wave] = incl;
+    // backward: first head behind q (span + 1: none staged)
+    int first = kRunSortSpan + 1;
+    for (int q = q1 - 1; q >= q0; --q) first = head(q) ? q : first;
+    int incb = first;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_down(incb, o, kWave);
+        if (lane + o < kWave) incb = min(incb, v);
+    }
+    if (lane == 0) s_wave[1][wave] = incb;
+    __syncthreads();
+    {
+        int carry = __shfl_up(incl, 1, kWave);  // exclusive over the lanes in front of this one
+        if (lane == 0) carry = -1;
+        for (int w = 0; w < wave; ++w) carry = max(carry, s_wave[0][w]);
+        int run = carry;
+        for (int q = q0; q < q1; ++q) {
+            run = head(q) ? q : run;
+            s_rs[q] = (short)run;
+        }
+        int carryb = __shfl_down(incb, 1, kWave);  // exclusive over the lanes behind this one
+        if (lane == kWave - 1) carryb = kRunSortSpan + 1;
+        for (int w = wave + 1; w < 256 / kWave; ++w) carryb = min(carryb, s_wave[1][w]);
+        int nxt = carryb;
+        for (int q = q1 - 1; q >= q0; --q) {
+            s_re[q] = (short)nxt;  // the first head BEHIND q
+            nxt = head(q) ? q : nxt;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kRunSortChunk / 256; ++u) {
-        const int li = u * 256 + (int)threadIdx.x;  // index inside the chunk
+        const int li = u * 256 + t;  // index inside the chunk
         const int64_t i = base + li;
         if (i >= n) continue;
         const int qi = li + kRunSortHalo;
-        const uint32_t key = s_key[qi], ti = s_tau[qi];
-        int b = qi, t = qi + 1;
-        while (qi - b < kRunSortMax && s_key[b - 1] == key) --b;
-        while (t - qi < kRunSortMax && s_key[t] == key) ++t;
+        const int b = s_rs[qi], e = s_re[qi];
         int64_t pos = i;
-        if (t - b <= kRunSortMax && s_key[b - 1] != key && s_key[t] != key) {  // the whole run is in sight: rank by (time, index)
-            int rank = 0;  // tau >= 0: the fp32 bit patterns order like the values
-            for (int j = b; j < t; ++j) {
+        // the whole run in sight (its head is staged -- a head at staged position 0 counts only where the position in front of it is
+        // known: s_key[0] is a real key or the front of the batch -- and so is the head of the next run) and short enough: rank by (time, index)
+        if (b >= 0 && e <= kRunSortSpan && e - b <= kRunSortMax && e - b > 1) {
+            const uint32_t ti = s_tau[qi];  // tau >= 0: the fp32 bit patterns order like the values
+            int rank = 0;
+            int j = b;
+            for (; j + 4 <= e; j += 4) {
+                const uint32_t t0 = s_tau[j], t1 = s_tau[j + 1], t2 = s_tau[j + 2], t3 = s_tau[j + 3];
+                rank += (t0 < ti || (t0 == ti && j < qi)) ? 1 : 0;
+                rank += (t1 < ti || (t1 == ti && j + 1 < qi)) ? 1 : 0;
+                rank += (t2 < ti || (t2 == ti && j + 2 < qi)) ? 1 : 0;
+                rank += (t3 < ti || (t3 == ti && j + 3 < qi)) ? 1 : 0;
+            }
+            for (; j < e; ++j) {
                 const uint32_t tj = s_tau[j];
                 rank += (tj < ti || (tj == ti && j < qi)) ? 1 : 0;
             }
             pos = lo + b + rank;
         }
-        const uint2 e = in.evp[i];
-        out.evp[pos] = e;
+        const uint2 ev = in.evp[i];
+        out.evp[pos] = ev;
         if (frac) {
             out.rx[pos] = in.rx[i];
             out.ry[pos] = in.ry[i];

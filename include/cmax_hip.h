@@ -444,6 +444,11 @@ int cmax_debug_launch_floor(cmax_handle_t h, int pairs, cmax_stream_t stream);
 /* Tuning aid (tools/timeline.py; libraries built with -DCMAX_TIMELINE only, CMAX_ESTATE otherwise): device buffer of 2 x 4096 x 8
  * uint64 into which thread 0 of the event kernels' workgroups stamps the wall clock at its phase boundaries (NULL: off).       */
 int cmax_debug_timeline(void *device_buffer);
+/* Test aid (tests/test_gpu_fused.py::test_packed_order): copies the packed, sorted events of the current batch -- n_events x 2 uint32:
+ * [row | col << 12 | (time bin, or the time's residual beyond fp32) << 24,  bits of the fp32 normalised time] -- and the group starts
+ * the work list was cut from ([n_groups + 1] int32; NULL skips them; *n_groups_host receives their number: source tiles, x time bins
+ * / slabs on binned handles) into device buffers, on `stream`.  The layout is what DESIGN.md section 2 describes, not a stable ABI.  */
+int cmax_debug_packed_events(cmax_handle_t h, void *events_out, int *group_start_out, int *n_groups_host, cmax_stream_t stream);
 
 /* =============================================================================================
  * The optimiser's objective for patch-based flow in one call: what

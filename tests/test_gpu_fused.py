@@ -767,3 +767,41 @@ def test_rebinning_keeps_the_batch_counts_and_set_events_leaves_slab_order():
     h2.set_events(ev2)  # un-binned batch after a slabbed one: the patch search walks tile-major groups again
     loss, gm, count = h2.patch_search(np.array([[0, 32, 0, 48]]), (32, 48), np.zeros((1, 1, 2)), 1.0)
     assert int(count[0].item()) > 0
+
+
+@pytest.mark.parametrize("size,n,bins", [((64, 96), 50_000, 0), ((260, 346), 400_000, 0), ((48, 64), 600_000, 0), ((64, 96), 60_000, 4)])
+def test_packed_order(size, n, bins):
+    """The order cmax_set_events leaves: source tile (16 x 16) major; un-binned handles by pixel inside a tile and BY
+    TIME inside a pixel (k_run_time_sort: runs of up to 192 events -- the (48, 64) case holds ~195 per pixel, so both branches run);
+    binned handles by (tile, bin).  Every input event appears exactly once with its pixel and its normalised time."""
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=3)
+    h = E.CMaxHandle(size).set_events(ev, time_bin=bins)
+    packed, gs = h.packed_events()
+    assert packed.shape[0] == n and gs[0] == 0 and gs[-1] == n and (np.diff(gs) >= 0).all()
+    row, col = packed[:, 0] & 0xFFF, (packed[:, 0] >> 12) & 0xFFF
+    tau = packed[:, 1].astype(np.uint32).view(np.float32)
+    # the same multiset of (pixel, time) as the input
+    tn = ((ev[:, 2] - ev[:, 2].min()) / (ev[:, 2].max() - ev[:, 2].min())).astype(np.float32)
+    key_in = np.lexsort((tn, ev[:, 1].astype(np.int64), ev[:, 0].astype(np.int64)))
+    key_out = np.lexsort((tau, col, row))
+    np.testing.assert_array_equal(row[key_out], ev[key_in, 0].astype(np.int64))
+    np.testing.assert_array_equal(col[key_out], ev[key_in, 1].astype(np.int64))
+    np.testing.assert_array_equal(tau[key_out], tn[key_in])
+    # tile-major groups
+    ntc = (size[1] + 15) // 16
+    tile = (row >> 4) * ntc + (col >> 4)
+    group = np.searchsorted(gs, np.arange(n), side="right") - 1
+    if bins == 0:
+        np.testing.assert_array_equal(group, tile)
+        pix = ((row & 15) << 4) | (col & 15)
+        same = (tile[1:] == tile[:-1])
+        assert (pix[1:][same] >= pix[:-1][same]).all()  # by pixel inside a tile
+        run_id = np.concatenate([[0], np.cumsum((pix[1:] != pix[:-1]) | ~same)])
+        run_len = np.bincount(run_id)
+        same_run = run_id[1:] == run_id[:-1]
+        short = run_len[run_id[1:]] <= 192
+        assert (tau[1:][same_run & short] >= tau[:-1][same_run & short]).all()  # by time inside a pixel run
+        assert (run_len <= 192).any() and ((run_len > 192).any() == (n // (size[0] * size[1]) > 150))
+    else:
+        np.testing.assert_array_equal(group // bins, tile)
+        np.testing.assert_array_equal(group % bins, packed[:, 0] >> 24)
