@@ -52,7 +52,9 @@ class PatchFlowObjective:
                  flow_interpolation: str = "burgers", t0_flow_location: str = "middle", filter_type: str = "bilinear", sliced=None):
         """sliced: a distributed.TimeSlicedObjective around `handle` when the batch is time-sliced over ranks.  With the library's own
         communicator on the handle (RCCL) the native plan evaluates the whole batch (cmax_patch_plan_* exchange images + 2 n_patch
-        numbers); otherwise -- torch.distributed collectives -- the autograd-chained path below does the same two exchanges."""
+        numbers); otherwise -- torch.distributed collectives -- the autograd-chained path below does the same two exchanges.  That
+        fall-back has no exact Hessian-vector product (TorchWrapper then takes a difference quotient of the gradient, which on this
+        piecewise-smooth objective is dominated by the kinks at cell borders): prefer a first-order method there, or the RCCL plan."""
         if filter_type != "bilinear":
             raise NotImplementedError("only the bilinear patch filter (the shipped configs) is built")
         self.handle = handle
