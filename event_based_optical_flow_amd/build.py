@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("CMAX_LIB", os.path.join(PKG_DIR, "libcmax_hip.so"))
 OBJ_DIR = os.path.join(PKG_DIR, "_obj")  # objects: git-ignored (*.o) and not shipped to the GPU box (.gpurunignore)
 SOURCES = ["cmax_leaf.hip", "cmax_flow.hip", "cmax_fused.hip", "cmax_solver.hip", "cmax_comm.hip"]
 HEADERS = ["cmax_common.h", "cmax_image_kernels.h", "cmax_patch_kernels.h", "cmax_flow_dual.h", "cmax_search_kernels.h",
-           "cmax_sort_kernels.h", "cmax_event_kernels.inc", "cmax_comm.h", os.path.join("..", "..", "include", "cmax_hip.h")]
+           "cmax_sort_kernels.h", "cmax_radix_sort.h", "cmax_event_kernels.inc", "cmax_comm.h", os.path.join("..", "..", "include", "cmax_hip.h")]
 # -munsafe-fp-atomics: fp32/fp64 atomicAdd lower to global_atomic_add_f32/_f64 and ds_add_f32
 # (hardware atomics) instead of compare-and-swap loops.
 # -amdgpu-kernarg-preload-count=16: the first 16 dwords of a kernel's arguments arrive in SGPRs at wave launch (gfx940+) instead

@@ -38,6 +38,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "cmax_comm.h"
@@ -45,6 +46,7 @@
 #include "cmax_image_kernels.h"
 #include "cmax_search_kernels.h"
 #include "cmax_sort_kernels.h"
+#include "cmax_radix_sort.h"
 
 // Environment knobs (tuning experiments and A/B tests only; none changes results):
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
@@ -57,6 +59,7 @@
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
 //   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
 //   CMAX_PLAN_GRAPHS=1   replay the patch plan from captured hipGraphs (cmax_solver.hip)
+//   CMAX_SORT=radix | bucket   per-batch order by the stable radix sort (cmax_radix_sort.h) / the two-level counting sort, whatever the size
 namespace cmax {
 
 constexpr int kSparseSegment = 512;  // voxel K3: segments below this many events add straight to memory (no LDS accumulators)
@@ -67,6 +70,8 @@ constexpr int kWinCap = 8192;                 // LDS window capacity in 32-bit w
 constexpr int kAccCells = 3072;               // flow-gradient accumulator cells per channel in LDS (voxel K3): 12 (tile, bin) groups
 constexpr int kAccCellsDense = 768;           // the same for the dense K3 with owned tiles: 3 source tiles
 constexpr int kWinMaxW = 128;                 // widest window when the bounding box has to be clipped
+constexpr int64_t kRadixMinEvents = 8000000;  // batches from here on are ordered by the stable radix sort (cmax_radix_sort.h): 8M events 550 vs 556 us,
+                                              // 12M 765 vs 875, 20M 1177 vs 1419, 64M 3483 vs 4754 (profiles/r05_set_events.txt); below, the counting sort's fewer launches win
 constexpr int kShiftWordsMax = 512;           // words of cell offsets per (reference time, segment): 4 bits per slot of a big segment
 // (votes are accumulated as signed fixed point in the LDS windows: 12.20, big segments 13.19 -- kFixNS of cmax_event_kernels.inc)
 
@@ -190,6 +195,9 @@ struct cmax_handle_s {
     int *counts = nullptr;  // [nkeys + 1] events per tile -> tile offsets after the scan
     int *cursor = nullptr;  // [nkeys] per-tile cursor of the bucket pass, then active source pixels per tile
     int *scan_tmp = nullptr;  // [ceil(nkeys / 2048)] chunk sums of the scan
+    int *rs_hist = nullptr;   // radix sort (large batches): [digits][workgroups] + 1 histogram / offsets of one pass
+    int *rs_tmp = nullptr;    // ... chunk sums of its scan
+    int64_t rs_hist_cap = 0;
     int nkeys = 0, ntr = 0, ntc = 0;
     int *d_flags = nullptr;  // [0] any fractional source coordinate, [1] dropped events, [2] events kept from off the sensor (cmax_set_keep_outside)
     bool long_runs = false;  // >= 8 events per active source pixel on average: the dense K3 reduces runs serially per thread
@@ -1831,15 +1839,19 @@ k_finish_raw(const double *__restrict__ raw, int n_ref, ObjParams op, const doub
 // host-side orchestration
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of h->counts[0..m) in place, counts[m] = total
+// exclusive scan of counts[0 .. m) in place, counts[m] = total (tmp: ceil(m / 2048) + 1 ints)
+static void launch_scan_buf(int *counts, int m, int *tmp, hipStream_t s, int *nonzero = nullptr, int *total_out = nullptr) {
+    const int nchunk = div_up(m, kScanChunk);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nchunk), dim3(256), 0, s, counts, m, tmp, nonzero);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, tmp, nchunk, total_out ? total_out : counts + m);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nchunk), dim3(256), 0, s, counts, m, tmp);
+}
 static void launch_scan(cmax_handle_s *h, int m, hipStream_t s, int *nonzero = nullptr) {
     if (m <= 4096 && !nonzero) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, h->counts, m);
         return;
     }
-    const int nchunk = div_up(m, kScanChunk);
-    hipLaunchKernelGGL(k_scan_sums, dim3(nchunk), dim3(256), 0, s, h->counts, m, h->scan_tmp, nonzero);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, h->scan_tmp, nchunk, h->counts + m);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nchunk), dim3(256), 0, s, h->counts, m, h->scan_tmp);
+    launch_scan_buf(h->counts, m, h->scan_tmp, s, nonzero);
 }
 
 static float ref_fraction(int ref_mode, double frac) {
@@ -2475,16 +2487,99 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
         h->cap_alt = h->cap;
     }
 
-    const int grid = (int)div_up(n_in, (int64_t)kSortChunk);
-    const SortOut stage = {h->evp_alt, h->rx_alt, h->ry_alt, h->rl_alt, h->tau64_alt};
-    const SortOut fin = {h->evp, h->rx, h->ry, h->rl, h->tau64};
+    SortOut stage = {h->evp_alt, h->rx_alt, h->ry_alt, h->rl_alt, h->tau64_alt};
+    SortOut fin = {h->evp, h->rx, h->ry, h->rl, h->tau64};
     unsigned long long *keys = reduce_time ? reinterpret_cast<unsigned long long *>(h->d_tmm) : nullptr;
+    // Large batches: the STABLE radix sort (cmax_radix_sort.h) -- every pass streams, the events of a pixel come out by time without
+    // k_run_time_sort, and the packed order is a function of the batch alone.  Small ones (a few launches fewer) keep the counting sort.
+    static const char *sort_env = getenv("CMAX_SORT");
+    const bool radix = sort_env ? strcmp(sort_env, "radix") == 0 : n_in >= kRadixMinEvents;
+    if (radix) {
+        const RsKey key = {h->ntc, T, (T == 0 || T * 256 <= kTileKeysMax) ? 1 : 0};
+        const int ngroups_all = ntiles * (T > 0 ? T : 1);
+        int gb = 1;
+        while ((1 << gb) < ngroups_all) ++gb;
+        // Digits of <= kRsMaxDigitBits bits: a pass writes one stream per (workgroup, digit), and its time follows the number of streams
+        // (64M events: 1.41 ms per pass at 1024 digits, 0.53 at 32 -- cmax_radix_sort.h), so more, narrower passes win.
+        // Un-binned handles: the whole key (8 pixel bits + tile bits) in equal digits -- every digit of it follows from the source pixel
+        // alone.  Binned handles: the pixel byte first (the time bin, which needs the batch's extremes, sits above it), then the group bits.
+        int nb[8], sh[8], P = 0, shift = 0;
+        static const int digit_bits = getenv("CMAX_RS_BITS") ? std::min(kRsMaxDigitBits, std::max(2, atoi(getenv("CMAX_RS_BITS")))) : kRsMaxDigitBits;  // tuning only
+        auto split = [&](int total_bits) {
+            const int parts = div_up(total_bits, digit_bits);
+            for (int q = 0, done = 0; q < parts; ++q) {
+                const int bits = div_up(total_bits - done, parts - q);
+                nb[P] = bits;
+                sh[P++] = shift;
+                shift += bits;
+                done += bits;
+            }
+        };
+        if (T == 0) {
+            split(8 + gb);
+        } else {
+            if (key.fine) {
+                nb[P] = 8;
+                sh[P++] = 0;
+                shift = 8;
+            }
+            split(gb);
+        }
+        int maxbits = 0;
+        for (int q = 0; q < P; ++q) maxbits = std::max(maxbits, nb[q]);
+        const int nwg = (int)std::min<int64_t>(kRsMaxGroups, std::max<int64_t>(1, div_up(n_in, (int64_t)kRsChunk)));
+        const int64_t range = (int64_t)div_up(div_up(n_in, (int64_t)nwg), (int64_t)kRsThreads) * kRsThreads;
+        const int64_t need = ((int64_t)1 << maxbits) * nwg + 1;
+        if (need > h->rs_hist_cap) {
+            CMAX_CHECK_HIP(hipStreamSynchronize(s));
+            dev_free(&h->rs_hist);
+            dev_free(&h->rs_tmp);
+            h->rs_hist_cap = 0;
+            int rc = dev_alloc(h, &h->rs_hist, need);
+            if (!rc) rc = dev_alloc(h, &h->rs_tmp, div_up(need, (int64_t)kScanChunk) + 2);
+            if (rc) return rc;
+            h->rs_hist_cap = need;
+        }
+        hipLaunchKernelGGL(k_rs_clear, dim3(div_up(std::max(ntiles, 4), 256)), dim3(256), 0, s, h->d_active, ntiles, h->d_flags, first_flag, keys);
+        if (!key.fine && keys)  // (the first digit needs the time bin: the batch's extremes first)
+            hipLaunchKernelGGL((k_rs_time_extremes<SRC>), dim3(nwg), dim3(kRsThreads), 0, s, src, n_in, keys);
+        // pass q writes buffer (P - 1 - q) % 2 (0: the handle's own arrays, 1: the staging copy), so that the last pass lands in the own arrays.
+        // Re-binning reads the own arrays: when pass 0 would write them too, the two sets swap roles first (the source then IS the staging set).
+        if (!std::is_same<SRC, RawSource<float>>::value && !std::is_same<SRC, RawSource<double>>::value && (P - 1) % 2 == 0) {
+            std::swap(h->evp, h->evp_alt);
+            std::swap(h->rx, h->rx_alt);
+            std::swap(h->ry, h->ry_alt);
+            std::swap(h->rl, h->rl_alt);
+            std::swap(h->tau64, h->tau64_alt);
+            std::swap(stage, fin);
+        }
+        // the number of packed events (every pass's scan writes it again): where the other pipeline keeps its total, outside the histogram
+        // buffer the next pass overwrites
+        int *total = h->counts + ntiles;
+        for (int q = 0; q < P; ++q) {
+            const int D = 1 << nb[q], m = D * nwg;
+            const SortOut &out = (P - 1 - q) % 2 == 0 ? fin : stage;
+            const SortOut &in = (P - 1 - q) % 2 == 0 ? stage : fin;
+            if (q == 0) hipLaunchKernelGGL((k_rs_hist_src<SRC>), dim3(nwg), dim3(kRsThreads), (size_t)D * sizeof(int), s, src, n_in, range, key, nb[q], h->rs_hist, h->d_flags, keys);
+            else hipLaunchKernelGGL(k_rs_hist, dim3(nwg), dim3(kRsThreads), (size_t)D * sizeof(int), s, (const uint2 *)in.evp, (const int *)total, range, key, sh[q], nb[q], h->rs_hist);
+            launch_scan_buf(h->rs_hist, m, h->rs_tmp, s, nullptr, total);
+            const size_t lds = (size_t)D * (sizeof(int) + sizeof(unsigned long long));
+            if (q == 0) hipLaunchKernelGGL((k_rs_scatter_src<SRC>), dim3(nwg), dim3(kRsThreads), lds, s, src, n_in, range, key, nb[q], (const int *)h->rs_hist, (const int *)h->d_flags, out);
+            else hipLaunchKernelGGL(k_rs_scatter, dim3(nwg), dim3(kRsThreads), lds, s, in, (const int *)total, range, key, sh[q], nb[q], (const int *)h->rs_hist, (const int *)h->d_flags, out);
+            CMAX_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(k_rs_meta, dim3(div_up(n_in, 256)), dim3(256), 0, s, (const uint2 *)fin.evp, (const int *)total, key, ngroups_all, h->d_tile_start,
+                           T == 0 ? h->d_active : (int *)nullptr, std::max(1, ntiles), keys);
+        CMAX_CHECK_LAUNCH();
+    } else {
+    const int grid = (int)div_up(n_in, (int64_t)kSortChunk);
     hipLaunchKernelGGL(k_sort_clear, dim3(div_up(ntiles + 1, 256)), dim3(256), 0, s, h->counts, h->cursor, ntiles, h->d_flags, first_flag, keys);
     hipLaunchKernelGGL((k_bucket_hist<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, h->counts, h->d_flags, keys);
     launch_scan(h, ntiles, s);
     hipLaunchKernelGGL((k_bucket_scatter<SRC>), dim3(grid), dim3(kSortThreads), 0, s, src, n_in, h->ntc, ntiles, T, h->counts, h->cursor, h->d_flags, stage);
     hipLaunchKernelGGL(k_tile_sort, dim3(ntiles), dim3(kTileSortThreads), 0, s, ntiles, T, h->counts, stage, fin, h->d_tile_start, h->d_active, h->d_flags, keys);
     CMAX_CHECK_LAUNCH();
+    }
     if (T > 0 && h->slab_major) {  // slab-major group order (cmax_sort_kernels.h, S4b): final SoA -> staging SoA, the two swap roles
         const int ngroups = ntiles * T;
         hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(1024), 0, s, h->d_tile_start, ngroups, h->ntc, T, h->cursor);
@@ -2501,7 +2596,7 @@ static int sort_events(cmax_handle_s *h, const SRC &src, int64_t n_in, bool redu
     BatchReadback rb;
     rb.n_in = n_in;
     return build_segments(h, T > 0 ? 1 : 256, s, &rb, [&]() -> int {
-        if (T == 0 && run_sort) {
+        if (T == 0 && run_sort && !radix) {
             // pixel runs ordered by time: final SoA -> staging SoA, then the two swap roles (same capacities).  Runs on the GPU
             // while the host cuts the segments: it needs nothing from the host and changes nothing the host reads back.
             hipLaunchKernelGGL(k_run_time_sort, dim3(div_up(n_in, kRunSortChunk)), dim3(256), 0, s, fin, stage, h->counts + ntiles, h->d_flags);
@@ -2665,6 +2760,8 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->counts);
     dev_free(&h->cursor);
     dev_free(&h->scan_tmp);
+    dev_free(&h->rs_hist);
+    dev_free(&h->rs_tmp);
     dev_free(&h->d_segs);
     dev_free(&h->d_win);
     dev_free(&h->d_shifts);

@@ -115,6 +115,31 @@ struct RawSource {
         }
         return it;
     }
+    // the loads of full() on their own, and the arithmetic behind them: the radix sort issues the loads of its NEXT step before it
+    // works on the current one (cmax_radix_sort.h)
+    struct Fetched {
+        T x, y, t;
+    };
+    __device__ __forceinline__ Fetched fetch(int64_t i) const { return Fetched{ev[4 * i + 0], ev[4 * i + 1], ev[4 * i + 2]}; }
+    __device__ __forceinline__ SortItem resolve(const Fetched &f, int64_t) const {
+        SortItem it = classify(f.x, f.y);
+        if (it.ix >= 0) {
+            const double rxd = (double)f.x - (double)it.ix, ryd = (double)f.y - (double)it.iy;
+            it.rx = (float)rxd;
+            it.ry = (float)ryd;
+            it.rxl = (float)(rxd - (double)it.rx);
+            it.ryl = (float)(ryd - (double)it.ry);
+            double tmin = tmm[0], tmax = tmm[1];
+            if (keyed) {
+                const unsigned long long *k = reinterpret_cast<const unsigned long long *>(tmm);
+                tmin = sort_f64_unkey(~k[0]);
+                tmax = sort_f64_unkey(k[1]);
+            }
+            const double per = tmax - tmin;
+            it.tn = per > 0 ? ((double)f.t - tmin) / per : 0.0;
+        }
+        return it;
+    }
     __device__ __forceinline__ SortItem full(int64_t i) const {
         const T x = ev[4 * i + 0], y = ev[4 * i + 1];
         SortItem it = classify(x, y);
@@ -153,6 +178,34 @@ struct PackedSource {
         it.iy = (int)((pk >> 12) & 0xFFFu);
         it.frac = false;
         it.outside = false;
+        return it;
+    }
+    struct Fetched {
+        uint32_t pk;
+        float rx, ry;
+        float2 lo;
+        double tn;
+    };
+    __device__ __forceinline__ Fetched fetch(int64_t i) const {
+        Fetched f;
+        f.pk = evp[i].x;
+        f.rx = has_frac ? rx[i] : 0.f;
+        f.ry = has_frac ? ry[i] : 0.f;
+        f.lo = has_frac ? rl[i] : make_float2(0.f, 0.f);
+        f.tn = tau64[i];
+        return f;
+    }
+    __device__ __forceinline__ SortItem resolve(const Fetched &f, int64_t) const {
+        SortItem it;
+        it.ix = (int)(f.pk & 0xFFFu);
+        it.iy = (int)((f.pk >> 12) & 0xFFFu);
+        it.frac = false;
+        it.outside = false;
+        it.rx = f.rx;
+        it.ry = f.ry;
+        it.rxl = f.lo.x;
+        it.ryl = f.lo.y;
+        it.tn = f.tn;
         return it;
     }
     __device__ __forceinline__ SortItem full(int64_t i) const {

@@ -16,7 +16,7 @@ if not files:
 d = collections.defaultdict(list)
 for row in csv.DictReader(open(files[0])):
     d[row["Kernel_Name"]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
-rows = [(k, v) for k, v in d.items() if re.search(r"cmax::k_(sort|bucket|scan|tile|run|slab|tmm)", k)]
+rows = [(k, v) for k, v in d.items() if re.search(r"cmax::k_(sort|bucket|scan|tile|run|slab|tmm|rs)", k)]
 rows.sort(key=lambda kv: -sum(kv[1]))
 with open(out + "/kernel_stats.txt", "w") as f:
     for k, v in rows:
