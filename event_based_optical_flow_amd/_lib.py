@@ -99,6 +99,7 @@ SIGNATURES = {
     "cmax_contrast": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "cmax_total_variation": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "cmax_flow_step": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_int, c_vp, c_vp]),
+    "cmax_set_leaf_deterministic": (c_int, [c_int]),
     "cmax_flow_step_adj": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_int, c_vp, c_vp, c_vp]),
     "cmax_voxel_construct": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cmax_voxel_construct_adj": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -2,6 +2,8 @@
 // time bins, and the adjoints.  Restates src/utils/flow_utils.py:99-161 (voxel), 567-639 (Burgers),
 // 439-493 (upwind) as one gather kernel per step: each thread owns one pixel and reads its
 // 4-neighbourhood (the reference materialises ~30 intermediate ATen tensors per step).
+#include <atomic>
+
 #include "cmax_common.h"
 #include "cmax_flow_dual.h"
 #include "cmax_patch_kernels.h"
@@ -357,6 +359,9 @@ static int flow_step(const T *F, int H, int W, double dt, int scheme, T *out, hi
     return 0;
 }
 
+// cmax_set_leaf_deterministic: the stand-alone adjoint entries take the order-free step kernels (no handle to read a mode from)
+static std::atomic<int> g_leaf_det{0};
+
 template <typename T>
 static int flow_step_adj(const T *F, int H, int W, double dt, int scheme, const T *gout, T *gF, hipStream_t s) {
     const int64_t hw = (int64_t)H * W;
@@ -366,6 +371,20 @@ static int flow_step_adj(const T *F, int H, int W, double dt, int scheme, const 
         return 0;
     }
     const T sg = dt > 0 ? (T)1 : (T)-1, tau = (T)fabs(dt);
+    if (g_leaf_det.load(std::memory_order_relaxed)) {  // every destination pixel evaluates the scatter of its five sources itself: no atomics
+        StepJobs<T> jobs = {};
+        jobs.src[0] = F;
+        jobs.gout[0] = gout;
+        jobs.dst[0] = gF;
+        jobs.s[0] = sg;
+        const dim3 agrid(div_up(H, kAdjTileH) * div_up(W, kAdjTileW), 1);
+        if (scheme == CMAX_SCHEME_BURGERS)
+            hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_BURGERS, true>), agrid, dim3(kAdjThreads), 0, s, jobs, 1, H, W, tau);
+        else
+            hipLaunchKernelGGL((k_flow_step_adj_tiled<T, CMAX_SCHEME_UPWIND, true>), agrid, dim3(kAdjThreads), 0, s, jobs, 1, H, W, tau);
+        CMAX_CHECK_LAUNCH();
+        return 0;
+    }
     const int grid = div_up(hw, 256);
     if (scheme == CMAX_SCHEME_BURGERS)
         hipLaunchKernelGGL((k_flow_step_adj<T, CMAX_SCHEME_BURGERS>), dim3(grid), dim3(256), 0, s, F, H, W, sg, tau, gout, gF);
@@ -581,6 +600,8 @@ int cmax_flow_step(const void *F, int dtype, int H, int W, double dt, int scheme
     return CMAX_EINVAL;
 }
 
+int cmax_set_leaf_deterministic(int enable) { return g_leaf_det.exchange(enable != 0 ? 1 : 0); }
+
 int cmax_flow_step_adj(const void *F, int dtype, int H, int W, double dt, int scheme, const void *gout, void *gF,
                        cmax_stream_t stream) {
     CMAX_REQUIRE(F && gout && gF && H > 0 && W > 0, "flow_step_adj");
@@ -604,8 +625,8 @@ int cmax_voxel_construct_adj(const void *V, int dtype, int Tn, int t0, int H, in
                              cmax_stream_t stream) {
     CMAX_REQUIRE(V && gV && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj");
     CMAX_REQUIRE(scheme == CMAX_SCHEME_BURGERS || scheme == CMAX_SCHEME_UPWIND, "voxel_construct_adj: scheme");
-    if (dtype == CMAX_F32) return voxel_construct_adj<float>((const float *)V, Tn, t0, H, W, scheme, (float *)gV, (float *)gF, (hipStream_t)stream);
-    if (dtype == CMAX_F64) return voxel_construct_adj<double>((const double *)V, Tn, t0, H, W, scheme, (double *)gV, (double *)gF, (hipStream_t)stream);
+    if (dtype == CMAX_F32) return voxel_construct_adj<float>((const float *)V, Tn, t0, H, W, scheme, (float *)gV, (float *)gF, (hipStream_t)stream, g_leaf_det.load() != 0);
+    if (dtype == CMAX_F64) return voxel_construct_adj<double>((const double *)V, Tn, t0, H, W, scheme, (double *)gV, (double *)gF, (hipStream_t)stream, g_leaf_det.load() != 0);
     set_error("voxel_construct_adj: dtype");
     return CMAX_EINVAL;
 }
@@ -625,9 +646,9 @@ int cmax_voxel_construct_adj_tan(const void *V, const void *dV, int dtype, int T
     CMAX_REQUIRE(V && dV && gV && dgV && Tn > 0 && t0 >= 0 && t0 < Tn && H > 0 && W > 0, "voxel_construct_adj_tan");
     CMAX_REQUIRE(scheme == CMAX_SCHEME_BURGERS || scheme == CMAX_SCHEME_UPWIND, "voxel_construct_adj_tan: scheme");
     if (dtype == CMAX_F32)
-        return voxel_construct_adj_tan<float>((const float *)V, (const float *)dV, Tn, t0, H, W, scheme, (float *)gV, (float *)dgV, (float *)gF, (float *)dgF, (hipStream_t)stream);
+        return voxel_construct_adj_tan<float>((const float *)V, (const float *)dV, Tn, t0, H, W, scheme, (float *)gV, (float *)dgV, (float *)gF, (float *)dgF, (hipStream_t)stream, g_leaf_det.load() != 0);
     if (dtype == CMAX_F64)
-        return voxel_construct_adj_tan<double>((const double *)V, (const double *)dV, Tn, t0, H, W, scheme, (double *)gV, (double *)dgV, (double *)gF, (double *)dgF, (hipStream_t)stream);
+        return voxel_construct_adj_tan<double>((const double *)V, (const double *)dV, Tn, t0, H, W, scheme, (double *)gV, (double *)dgV, (double *)gF, (double *)dgF, (hipStream_t)stream, g_leaf_det.load() != 0);
     set_error("voxel_construct_adj_tan: dtype");
     return CMAX_EINVAL;
 }

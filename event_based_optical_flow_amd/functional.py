@@ -269,6 +269,12 @@ class _FlowStepFn(torch.autograd.Function):
         return gF, None, None
 
 
+def set_leaf_deterministic(enable: bool = True) -> bool:
+    """Process-wide (cmax_set_leaf_deterministic): the adjoints of `flow_step` / `construct_dense_flow_voxel` (and the second-order
+    adjoint) accumulate without atomics, in a fixed order -- bit-identical gradients from run to run.  Returns the previous setting."""
+    return bool(_lib.load().cmax_set_leaf_deterministic(int(bool(enable))))
+
+
 def flow_step(flow, dt: float, scheme: str):
     """One Burgers / upwind step on a [2,H,W] flow (src/utils/flow_utils.py:567-639 / 439-493)."""
     _lib.require_gpu()

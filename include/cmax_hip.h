@@ -382,11 +382,16 @@ int cmax_objective_hvp_dist(cmax_handle_t h, const cmax_objective_t *desc_host, 
  * cmax_objective_hvp is covered as well (round 3: integer tangent-vote images, integer accumulation of the second-order gather).
  * A patch plan on a deterministic handle (cmax_patch_plan_evaluate / _hvp) is covered too: the interpolation and its adjoint are
  * gathers, the adjoint sweeps of the voxel chain run order-free step kernels (every destination pixel evaluates the scatter of
- * its five sources itself instead of LDS atomics), the tail is one workgroup.  Not covered: the stand-alone leaf entries
- * cmax_flow_step_adj / cmax_voxel_construct_adj[_tan] (no handle to read the mode from; fp64 LDS atomics, last-bit differences);
- * across ranks (cmax_objective_dist) the result is as repeatable as RCCL's reduction order.                          */
+ * its five sources itself instead of LDS atomics), the tail is one workgroup.  The stand-alone leaf entries
+ * cmax_flow_step_adj / cmax_voxel_construct_adj[_tan] have no handle to read the mode from: cmax_set_leaf_deterministic (round 5, a
+ * process-wide switch) makes them take the same order-free step kernels.  Across ranks (cmax_objective_dist) the result is as
+ * repeatable as RCCL's reduction order.                                                                                          */
 int cmax_set_deterministic(cmax_handle_t h, int enable);
 int cmax_get_deterministic(cmax_handle_t h, int *enabled);
+/* Process-wide: the adjoint leaf operators of the propagation step and of the voxel chain (cmax_flow_step_adj,
+ * cmax_voxel_construct_adj, cmax_voxel_construct_adj_tan) accumulate without atomics, in a fixed order -- bit-identical results from
+ * run to run (default 0: global / LDS atomics, last-bit differences).  Returns the previous setting.                              */
+int cmax_set_leaf_deterministic(int enable);
 
 /* Per-kernel-class timing for bench.py's roofline: when enabled every launch of the four hot kernels
  * is bracketed by HIP events ON THE LAUNCH STREAM.  enable = 1: one launch per bracket (results stay

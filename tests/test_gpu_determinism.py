@@ -185,3 +185,40 @@ def test_patch_plan_bit_repeatable(golden, tag):
     assert abs(loss - loss_d) <= 1e-6 * abs(loss_d)
     assert rel_max(grad, grad_d) <= 1e-5
     assert rel_max(hv, hv_d) <= 2e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("scheme", ["burgers", "upwind"])
+def test_leaf_adjoints_bit_repeatable(dtype, scheme):
+    """cmax_set_leaf_deterministic (round 5): the stand-alone adjoints of the propagation step and of the voxel chain -- which have no
+    handle to read a mode from -- take the order-free step kernels: three runs, identical bytes, and equal to the default (atomic)
+    form to accumulation noise."""
+    from event_based_optical_flow_amd import functional as F
+
+    H, W, Tn = 70, 93, 7
+    rng = np.random.default_rng(17)
+    flow = torch.tensor(rng.normal(0.0, 0.8, (2, H, W)), dtype=dtype, device="cuda")
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+
+    def grads():
+        f = flow.clone().requires_grad_()
+        V = F.construct_dense_flow_voxel(f, Tn, scheme, "middle")
+        cot = torch.tensor(np.random.default_rng(3).normal(size=tuple(V.shape)), dtype=dtype, device="cuda")
+        (g_vox,) = torch.autograd.grad((V * cot).sum(), f)
+        f2 = flow.clone().requires_grad_()
+        out = F.flow_step(f2, -0.3, scheme)
+        (g_step,) = torch.autograd.grad((out * cot[0]).sum(), f2)
+        torch.cuda.synchronize()
+        return g_vox.cpu().numpy(), g_step.cpu().numpy()
+
+    ref_vox, ref_step = grads()  # default mode
+    prev = F.set_leaf_deterministic(True)
+    try:
+        assert prev is False
+        runs = [grads() for _ in range(3)]
+    finally:
+        F.set_leaf_deterministic(False)
+    for gv, gs in runs[1:]:
+        assert gv.tobytes() == runs[0][0].tobytes() and gs.tobytes() == runs[0][1].tobytes()
+    assert np.abs(runs[0][0] - ref_vox).max() <= tol * np.abs(ref_vox).max()
+    assert np.abs(runs[0][1] - ref_step).max() <= tol * np.abs(ref_step).max()
