@@ -76,6 +76,9 @@ WORKLOADS = {
     "cfg2_batch8": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="batch", batch=8,
                         desc="cfg2 through cmax_objective_batch: 8 candidate thetas per call, one launch of each kernel (blockIdx.z = candidate); "
                              "ms_per_step and events/s are PER EVALUATION (8 per call)"),
+    "cfg2_batch32": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, form="batch", batch=32,
+                         desc="cfg2 through cmax_objective_batch: 32 candidate thetas per call -- the chunk the solver's grid initialisers use "
+                              "(solver/translation_search.py); ms_per_step and events/s are PER EVALUATION (32 per call)"),
     "cfg2_theta80": dict(H=260, W=346, n=1_000_000, model="2d-translation", cost="image_variance", sigma=0.0, theta=(80.0, -50.0), slabs=4,
                          desc="cfg2 at a large motion: theta = (80, -50) px over the batch, events in 4 time slabs (cmax_set_time_slabs: "
                               "windows of the source tiles' size + 20 x 13 px)"),
@@ -721,7 +724,7 @@ def main():
         # N = 1: the other single-GPU configurations, cfg5 as BASELINE states it on ONE GPU (the N = 1 point of its strong-scaling
         # curve), a working set larger than the Infinity Cache, and the headline's second rows (blur; sharp image)
         names = ([w for w in ("cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm", "cfg2_raw", "cfg2_host_result", "cfg2_sigma1", "cfg2_structured",
-                              "cfg2_theta80", "cfg2_theta150", "cfg2_batch8", "cfg3_rough", "cfg5_rough")
+                              "cfg2_theta80", "cfg2_theta150", "cfg2_batch8", "cfg2_batch32", "cfg3_rough", "cfg5_rough")
                   if w != args.workload]
                  if world == 1 else ["cfg5_strong"])
         for wname in names:
