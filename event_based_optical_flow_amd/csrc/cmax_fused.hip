@@ -214,6 +214,11 @@ struct cmax_handle_s {
     int *d_active = nullptr;  // [ntiles] source pixels that hold events, per tile (un-binned order; written by k_tile_sort)
     int4 *d_segs = nullptr;       // [nseg] (begin, count, first source tile, tiles spanned): work items of the event kernels
     int4 *d_win = nullptr;        // [4][nseg] LDS windows of the last objective vote (K1 -> K3 of the same evaluation)
+    // compact copy of the sorted events, one region per segment of the work list (EventLoads in cmax_event_kernels.inc): big segments of
+    // un-binned handles; valid for the current work list only (build_segments)
+    char *cev = nullptr;
+    int64_t cev_cap = 0;          // regions allocated
+    bool compact = false;
     // cmax_objective_batch: K candidate motions per launch (allocated on first use, sized for batch_cap candidates)
     float *bimg = nullptr;        // [2 buffers][batch_cap][n_ref <= 4][npix] vote images
     double *braw = nullptr;       // [batch_cap][4][kRawStride] raw sums
@@ -1878,10 +1883,11 @@ template <int MODEL>
 static void launch_vote(cmax_handle_s *h, const EvView &ev, const WarpParams &wp, const RefArgs &ra, int n_ref, hipStream_t s, int nz = 1) {
     const dim3 grid(8 * ((h->nseg + 7) / 8), n_ref, nz);  // z: candidate motions of cmax_objective_batch
     ProfScope prof(h, kProfVote, s);
+    const char *cev = (h->compact && h->big && MODEL != CMAX_MODEL_VOXEL) ? h->cev : nullptr;  // 6-byte events, one region per segment
 #define CMAX_LAUNCH_VOTE(NS, FRAC)                                                                                           \
     do {                                                                                                                    \
-        if (ra.musum[0]) hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC, true>), grid, dim3(NS::kThr), 0, s, h->d_segs, h->nseg, ev.ev, ev, wp, ra); \
-        else hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, h->d_segs, h->nseg, ev.ev, ev, wp, ra);     \
+        if (ra.musum[0]) hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC, true>), grid, dim3(NS::kThr), 0, s, h->d_segs, h->nseg, ev.ev, cev, ev, wp, ra); \
+        else hipLaunchKernelGGL((NS::k_vote<MODEL, FRAC>), grid, dim3(NS::kThr), 0, s, h->d_segs, h->nseg, ev.ev, cev, ev, wp, ra);     \
     } while (0)
     static const int force = forced_ns("CMAX_VOTE_NS");
     for (int rep = 0; rep < h->prof_repeat; ++rep) {
@@ -1922,12 +1928,13 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     const int nseg = seg_n < 0 ? h->nseg : seg_n;
     const dim3 grid(8 * ((nseg + 7) / 8) + (fold == kFoldStatsInside ? ra.stat_blocks : 0), n_ref, nz);
     ProfScope prof(h, kProfGrad, s);
+    const char *cev = (h->compact && h->big && MODEL != CMAX_MODEL_VOXEL) ? h->cev + (int64_t)seg0 * b512::kCompactStride : nullptr;
     if (h->deterministic) {  // one workgroup size, two ways of obtaining dL/dIWE (objective_finish runs the unfused image path)
 #define CMAX_LAUNCH_DET(FRAC, FOLD)                                                                                                         \
     do {                                                                                                                                    \
-        if (h->big) hipLaunchKernelGGL((b512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(b512::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
-        else if (h->mid) hipLaunchKernelGGL((m512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(m512::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
-        else hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
+        if (h->big) hipLaunchKernelGGL((b512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(b512::kThr), 0, s, segs, nseg, ev.ev, cev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
+        else if (h->mid) hipLaunchKernelGGL((m512::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(m512::kThr), 0, s, segs, nseg, ev.ev, cev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
+        else hipLaunchKernelGGL((t256::k_grad<MODEL, FRAC, FOLD, kGradDet>), grid, dim3(t256::kThr), 0, s, segs, nseg, ev.ev, cev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result); \
     } while (0)
         if (h->has_frac) {
             if (fold == kFoldStats) CMAX_LAUNCH_DET(true, kFoldStats);
@@ -1944,7 +1951,7 @@ static void launch_grad(cmax_handle_s *h, const EvView &ev, const WarpParams &wp
     // owned groups (dense / voxel, one reference time, group-aligned work list): LDS accumulators + plain stores
     const bool strided = MODEL == CMAX_MODEL_DENSE && !(h->long_runs && h->n_time_bin == 0);
 #define CMAX_LAUNCH_GRAD_L(NS, FRAC, FOLD, VARIANT) \
-    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, segs, nseg, ev.ev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result)
+    hipLaunchKernelGGL((NS::k_grad<MODEL, FRAC, FOLD, VARIANT>), grid, dim3(NS::kThr), 0, s, segs, nseg, ev.ev, cev, (const int4 *)ra.win, ra.stat_blocks, ev, wp, ra, op, h->d_stat, gpart, gflow, result)
 #define CMAX_LAUNCH_GRAD(NS, FRAC, FOLD)                                      \
     do {                                                                      \
         if constexpr (MODEL == CMAX_MODEL_DENSE) {                            \
@@ -2463,6 +2470,23 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         CMAX_CHECK_HIP(hipMemcpyAsync(h->d_segs, h->hp_segs, segs.size() * sizeof(int4), hipMemcpyHostToDevice, s));
         CMAX_CHECK_HIP(hipEventRecord(h->segs_copied, s));
     }
+    // Big segments of an un-binned handle: the compact copy the hot kernels read (6 B/event, one aligned region per segment).
+    // CMAX_COMPACT=0 switches it off (A/B runs).
+    static const int compact_env = getenv("CMAX_COMPACT") ? atoi(getenv("CMAX_COMPACT")) : 1;
+    h->compact = false;
+    if (h->big && T == 1 && !slab && h->n_time_bin == 0 && h->nseg > 0 && compact_env != 0) {
+        if (h->nseg > h->cev_cap) {
+            dev_free(&h->cev);
+            h->cev_cap = 0;
+            rc = dev_alloc(h, &h->cev, (int64_t)h->nseg * b512::kCompactStride);
+            if (rc) return rc;
+            h->cev_cap = h->nseg;
+        }
+        hipLaunchKernelGGL((b512::k_pack_compact<0>), dim3(h->nseg), dim3(b512::kThr), 0, s, (const int4 *)h->d_segs, h->nseg, (const uint2 *)h->evp, h->ntc,
+                           h->cev, h->d_flags + 3);
+        CMAX_CHECK_HIP(hipGetLastError());
+        h->compact = true;
+    }
     return 0;
 }
 
@@ -2774,6 +2798,7 @@ int cmax_destroy(cmax_handle_t h) {
     dev_free(&h->ry);
     dev_free(&h->rl);
     dev_free(&h->tau64);
+    dev_free(&h->cev);
     dev_free(&h->evp_alt);
     dev_free(&h->rx_alt);
     dev_free(&h->ry_alt);
