@@ -512,8 +512,15 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
         // per channel, instead of 64-bit per-lane pointer arithmetic (the field is < 4 GiB: checked by the host)
         const unsigned off = (unsigned)w.src * 4u;
         const char *m0 = reinterpret_cast<const char *>(wp.motion), *m1 = reinterpret_cast<const char *>(wp.motion + hw);
+#ifdef CMAX_AB_NOFLOW  // (A/B builds only, profiles/r05_ablation.txt 8: no flow reads at all -- what the dense kernels pay for them)
+        w.f0 = 0.25f + 1e-9f * (float)off;
+        w.f1 = -0.125f;
+        (void)m0;
+        (void)m1;
+#else
         w.f0 = *reinterpret_cast<const float *>(m0 + off);
         w.f1 = *reinterpret_cast<const float *>(m1 + off);
+#endif
         dx = fmaf(-w.dt, w.f0, dx);  // x' = x - dt*F[0,ix,iy], src/warp.py:305-306
         dy = fmaf(-w.dt, w.f1, dy);
     }
