@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/microbench_lds.hip -o tools/microbench_lds
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 __device__ __forceinline__ unsigned hash(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
@@ -21,6 +22,7 @@ __global__ void __launch_bounds__(256) k_lds(float *out, int per_thread) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     unsigned h = hash(t);
+    float acc = 0.f;
     for (int i = 0; i < per_thread; ++i) {
         h = h * 1664525u + 1013904223u;
         unsigned p = (h >> 8) & 4095u;
@@ -44,6 +46,8 @@ __global__ void __launch_bounds__(256) k_lds(float *out, int per_thread) {
             atomicAdd(&wu[p + 64], 3u);
             atomicAdd(&wu[p + 65], 3u);
         }
+        if (MODE == 11) acc += w[p] + w[p + 1] + w[p + 64] + w[p + 65];  // the K3 gather pattern (plain reads)
+        if (MODE == 12) { atomicAdd(&wu[p], 3u); atomicAdd(&wu[p + 1], 3u); atomicAdd(&wu[p + 65], 3u); atomicAdd(&wu[p + 66], 3u); }  // odd row stride
         if (MODE == 10) {
             atomicAdd(reinterpret_cast<unsigned long long *>(w) + (p >> 1), 0x0000000300000005ull);
             atomicAdd(reinterpret_cast<unsigned long long *>(w) + (p >> 1) + 32, 0x0000000300000005ull);
@@ -52,16 +56,17 @@ __global__ void __launch_bounds__(256) k_lds(float *out, int per_thread) {
     __syncthreads();
     float s = 0;
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) s += w[i];
-    if (s == -1.f) out[0] = s;
+    if (s + acc == -1.f) out[0] = s;
 }
 
-int main() {
+int main(int argc, char **argv) {
     float *out;
     if (hipMalloc(&out, 1024) != hipSuccess) return 1;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    const int blocks = 2048, per = 32;
+    // argv[1]: operations per thread (default 32 = the round-1 figures, launch-dominated: 5-7 us per launch; 2048 gives the sustained rate)
+    const int blocks = 2048, per = argc > 1 ? atoi(argv[1]) : 32;
     auto run = [&](const char *name, auto kern, double mult) {
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, per);
         (void)hipDeviceSynchronize();
@@ -87,5 +92,7 @@ int main() {
     run("u64 random", k_lds<8>, 1);
     run("u32 random 2x2 quads (per quad)", k_lds<9>, 1);
     run("u64 pairs = 2x2 quad (per quad)", k_lds<10>, 1);
+    run("plain reads 2x2 quads (per quad)", k_lds<11>, 1);
+    run("u32 2x2 quads, odd row stride (per quad)", k_lds<12>, 1);
     return 0;
 }
