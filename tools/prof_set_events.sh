@@ -16,11 +16,11 @@ if not files:
 d = collections.defaultdict(list)
 for row in csv.DictReader(open(files[0])):
     d[row["Kernel_Name"]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
-rows = [(k, v) for k, v in d.items() if re.search(r"cmax::k_(sort|bucket|scan|tile|run|slab|tmm|rs)", k)]
+rows = [(k, v) for k, v in d.items() if re.search(r"cmax::(\w+::)?k_(sort|bucket|scan|tile|run|slab|tmm|rs|pack)", k)]
 rows.sort(key=lambda kv: -sum(kv[1]))
 with open(out + "/kernel_stats.txt", "w") as f:
     for k, v in rows:
-        name = re.search(r"cmax::(k_\w+)", k).group(1)
+        name = re.search(r"cmax::(?:\w+::)?(k_\w+)", k).group(1)
         v = sorted(v)
         line = "[%s] %-20s calls %4d  median %9.2f us  min %9.2f  max %9.2f" % (tag, name, len(v), v[len(v) // 2], v[0], v[-1])
         print(line); f.write(line + "\n")
