@@ -48,7 +48,7 @@
 #include "cmax_sort_kernels.h"
 #include "cmax_radix_sort.h"
 
-// Environment knobs (tuning experiments and A/B tests only; none changes results):
+// Environment knobs (tuning experiments and A/B tests only; none changes results beyond rounding):
 //   CMAX_NO_OWNED=1      never build the group-aligned "owned groups" work list (cmax_set_events)
 //   CMAX_NO_RUN_SORT=1   leave the events of a source pixel in the order the tile sort produced (no ordering by time)
 //   CMAX_VOTE_NS / CMAX_GRAD_NS = 256 | 512 | 1024   force the workgroup size of K1 / K3
@@ -59,6 +59,8 @@
 //   CMAX_NSUB=n          statistics sub-accumulators (cache lines) per image
 //   CMAX_TAN2=0 | 1      2-DoF tangent-image path: never / also without a communicator
 //   CMAX_PLAN_GRAPHS=1   replay the patch plan from captured hipGraphs (cmax_solver.hip)
+//   CMAX_COMPACT=0       big segments read the plain 8-byte events instead of the 4.5-byte compact copy (fp32 time instead of 24-bit fixed point)
+//   CMAX_DEBUG_COMPACT=1 cmax_set_events synchronises behind k_pack_compact and fails if an event did not fit its region's coordinates
 //   CMAX_SORT=radix | bucket   per-batch order by the stable radix sort (cmax_radix_sort.h) / the two-level counting sort, whatever the size
 namespace cmax {
 
@@ -2492,6 +2494,16 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
         hipLaunchKernelGGL((b512::k_pack_compact<0>), dim3(h->nseg), dim3(b512::kThr), 0, s, (const int4 *)h->d_segs, h->nseg, (const uint2 *)h->evp, h->ntc,
                            h->cev, h->d_flags + 3);
         CMAX_CHECK_HIP(hipGetLastError());
+        static const bool debug_compact = getenv("CMAX_DEBUG_COMPACT") != nullptr;
+        if (debug_compact) {  // (k_pack_compact raises d_flags[3] when an event lies outside its segment's tile row / 8-tile span: never)
+            int bad = 0;
+            CMAX_CHECK_HIP(hipMemcpyAsync(&bad, h->d_flags + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+            CMAX_CHECK_HIP(hipStreamSynchronize(s));
+            if (bad) {
+                set_error("k_pack_compact: an event does not fit the compact coordinates of its segment");
+                return CMAX_ESTATE;
+            }
+        }
         h->compact = true;
     }
     return 0;
