@@ -191,7 +191,9 @@ int cmax_destroy(cmax_handle_t h);
  * the sensor (or NaN) are dropped.  If have_tminmax, (tmin, tmax) are the GLOBAL batch extremes
  * (multi-GPU time slices); otherwise they are reduced from this call's events (all of them) on the
  * device.  n_time_bin > 0 precomputes the voxel bin of every event with the reference's fp64 edge
- * arithmetic (src/warp.py:342-345).  Blocks once (work list sized on the host); 0.16 ms per 1M events. */
+ * arithmetic (src/warp.py:342-345).  Blocks once (work list sized on the host); 0.10 ms per 1M events.
+ * Device memory per event: 64 B (packed events, fp64 times, the sort's staging copy) + 4.5 B for the compact copy the hot kernels read
+ * when the work list is cut into big segments (un-binned batches of >= 8M events, or by the work-list rule from ~4M). */
 int cmax_set_events(cmax_handle_t h, const void *events, int dtype, int64_t n, int have_tminmax,
                     double tmin, double tmax, int n_time_bin, cmax_stream_t stream);
 int cmax_set_time_bins(cmax_handle_t h, int n_time_bin, cmax_stream_t stream);
