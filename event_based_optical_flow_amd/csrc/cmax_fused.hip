@@ -491,25 +491,38 @@ struct Warped {
     float f0, f1;  // dense / voxel: the flow at the source pixel (phase_warp bounds the rounding of dt * f with it)
 };
 
+// One event as the warp sees it, whichever way it was stored (plain 8-byte event: absolute coordinates, zero bases; compact event of a
+// big segment: coordinates relative to the segment's tile strip, bases from the region's header -- cmax_event_kernels.inc).
+struct EvDec {
+    unsigned ixr, iyr;  // source row / column minus EvBase::row / col
+    unsigned top;       // top byte of the plain packed word (voxel: the time bin)
+    unsigned key;       // (row | col << 12 [| bin << 24]) absolute: the run key of the flow-gradient reduction (K3)
+    float tmd;          // tau - d: calculate_dt before the time scale, rounded once
+};
+struct EvBase {  // workgroup-uniform
+    unsigned row, col;  // what ixr / iyr are relative to (0 for plain events)
+    unsigned src;       // row * W + col
+};
+
 // MODEL: -1 none (orig_iwe), 0 2-DoF, 1 dense, 2 voxel
 template <int MODEL, bool FRAC>
-__device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i, bool valid, const WarpParams &wp, float tscale, float th0, float th1) {
+__device__ __forceinline__ Warped warp_one(const EvView &ev, const EvDec &e, const EvBase &eb, int64_t i, bool valid, const WarpParams &wp, float tscale, float th0,
+                                           float th1) {
     Warped w;
-    const uint32_t pk = e.x;
-    const int ix = (int)(pk & 0xFFFu), iy = (int)((pk >> 12) & 0xFFFu);
-    w.dt = (__uint_as_float(e.y) - wp.d) * tscale;  // calculate_dt, src/warp.py:254-259
+    const int ix = (int)e.ixr, iy = (int)e.iyr;
+    w.dt = e.tmd * tscale;  // calculate_dt, src/warp.py:254-259
     float dx = 0.f, dy = 0.f;
     if (FRAC && valid) {  // `valid` false: an empty slot of the caller (zero event), i may be outside the arrays
         dx = ev.rx[i];
         dy = ev.ry[i];
     }
-    w.src = (int)__umul24((unsigned)ix, (unsigned)wp.W & 0xFFFFFFu) + iy;  // 12-bit x 13-bit: v_mul_u32_u24 (full rate; v_mul_lo_u32 runs at a quarter)
+    w.src = (int)(__umul24((unsigned)ix, (unsigned)wp.W & 0xFFFFFFu) + (unsigned)iy + eb.src);  // 12-bit x 13-bit: v_mul_u32_u24 (full rate; v_mul_lo_u32 runs at a quarter)
     if (MODEL == CMAX_MODEL_2DOF) {
         dx = fmaf(w.dt, th0, dx);  // x' = x + dt*theta0, src/warp.py:506-515
         dy = fmaf(w.dt, th1, dy);
     } else if (MODEL == CMAX_MODEL_DENSE || MODEL == CMAX_MODEL_VOXEL) {
         const int hw = wp.H * wp.W;
-        if (MODEL == CMAX_MODEL_VOXEL) w.src += (int)(pk >> 24) * 2 * hw;  // (2 HW can exceed 24 bits: a full 32-bit multiply)
+        if (MODEL == CMAX_MODEL_VOXEL) w.src += (int)e.top * 2 * hw;  // (2 HW can exceed 24 bits: a full 32-bit multiply)
         // uniform base + unsigned 32-bit BYTE offset: one address instruction per event and a `global_load_dword v, voff, s[base]`
         // per channel, instead of 64-bit per-lane pointer arithmetic (the field is < 4 GiB: checked by the host)
         const unsigned off = (unsigned)w.src * 4u;
@@ -532,8 +545,8 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, uint2 e, int64_t i,
     w.a = dx - fx;
     w.b = dy - fy;
     const float cx = fminf(fmaxf(fx, -8192.f), 8192.f), cy = fminf(fmaxf(fy, -8192.f), 8192.f);
-    w.row = ix + (int)cx + wp.ph;
-    w.col = iy + (int)cy + wp.pw;
+    w.row = ix + (int)cx + (int)(eb.row + (unsigned)wp.ph);
+    w.col = iy + (int)cy + (int)(eb.col + (unsigned)wp.pw);
     return w;
 }
 
