@@ -118,3 +118,35 @@ def test_fractional_sources_on_big_segments(model):
     res, grad = h.evaluate(desc, motion)
     gate(f"{model} 8.2M events, fractional sources, reference time 1/3", h, res, grad, ref)
     h.close()
+
+
+def test_compact_copy_follows_the_work_list():
+    """The compact copy belongs to ONE work list: re-binning a big batch (binned work lists read the 8-byte events), returning to the
+    un-binned order, a smaller batch on the same handle (standard segments: no compact copy) and a big batch again must each evaluate
+    what the oracle does -- nothing may read a region packed for another cut."""
+    ev = E.utils.generate_events(N, SIZE[0], SIZE[1], 0.0, 0.05, seed=79)
+    flow = f32(E.utils.generate_smooth_flow(SIZE, 8, seed=1080))
+    desc = E.make_descriptor("image_variance", "dense-flow")
+    ref = orc.objective(ev, flow, "dense-flow", SIZE, cost="image_variance", sigma=0)
+    h = E.CMaxHandle(SIZE).set_events(ev)
+    res, grad = h.evaluate(desc, flow)
+    gate("big batch", h, res, grad, ref)
+    h.set_time_bins(4)  # (tile, bin) groups: the voxel layout of the same events
+    voxel = np.stack([flow] * 4)
+    vdesc = E.make_descriptor("image_variance", "dense-flow-voxel", time_bin=4)
+    vref = orc.objective(ev, voxel, "dense-flow-voxel", SIZE, cost="image_variance", sigma=0)
+    res, grad = h.evaluate(vdesc, voxel)
+    gate("the same batch in 4 time bins (voxel objective)", h, res, grad, vref)
+    h.set_time_bins(0)
+    res, grad = h.evaluate(desc, flow)
+    gate("back in the un-binned order", h, res, grad, ref)
+    small = E.utils.generate_events(600_000, SIZE[0], SIZE[1], 0.0, 0.05, seed=80)
+    h.set_events(small)
+    assert h.work_list_info()["segment_events"] < 4088
+    sref = orc.objective(small, flow, "dense-flow", SIZE, cost="image_variance", sigma=0)
+    res, grad = h.evaluate(desc, flow)
+    gate("a 600k-event batch on the same handle", h, res, grad, sref)
+    h.set_events(ev)
+    res, grad = h.evaluate(desc, flow)
+    gate("the big batch again", h, res, grad, ref)
+    h.close()
