@@ -20,6 +20,7 @@ its trajectories depend on Optuna's TPE sampler):
 These are host-side operations on a few hundred numbers between scales, not part of the hot path.
 """
 import logging
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -118,6 +119,8 @@ class PyramidalPatchContrastMaximization:
         self.search_history = []  # (scale, candidates, loss, picked index) of the per-patch re-initialisation
         self._handle: Optional[CMaxHandle] = None
         self._objectives: Dict[int, PatchFlowObjective] = {}
+        self._warper = self._imager = None  # built on first use by the metric / picture methods below
+        self.iwe_visualize_max_scale = solver_config.get("max_scale", 50)
 
     # -- reference API ---------------------------------------------------------------------------
     def set_previous_frame_best_estimation(self, previous_best):
@@ -284,14 +287,215 @@ class PyramidalPatchContrastMaximization:
             refined[i - 1] = pyramid_reduce(motion_per_scale[i])
         return refined
 
-    def motion_to_dense_flow(self, motion_per_scale: dict) -> np.ndarray:
-        """Finest-scale motion -> dense flow [2,H,W] in pixel per time unit (what the reference visualises)."""
+    def motion_to_dense_flow(self, motion_per_scale: dict, t_scale: float = 1.0) -> np.ndarray:
+        """Finest-scale motion -> dense flow [2,H,W] in pixel per time unit (patch_contrast_pyramid.py:464-516); time-aware solvers:
+        the flow voxel [time_bin,2,H,W] propagated from it at displacement scale (flow * t_scale through the Burgers / upwind chain,
+        divided by t_scale again)."""
         import torch
 
         from .. import functional as F
+        from ..utils.flow_utils import construct_dense_flow_voxel_torch
         from .patch_objective import patch_pad
 
         s = max(motion_per_scale)
         ps = self.scaled_patch_size[s]
-        m = torch.as_tensor(motion_per_scale[s], dtype=torch.float64, device="cuda")
-        return F.patch_to_dense(m, self.image_shape, ps, patch_pad(ps, ps, self.patch_shift)).cpu().numpy()
+        m = torch.as_tensor(np.asarray(motion_per_scale[s]), dtype=torch.float64, device="cuda")
+        dense = F.patch_to_dense(m, self.image_shape, ps, patch_pad(ps, ps, self.patch_shift))
+        if not self.is_time_aware:
+            return dense.cpu().numpy()
+        voxel = construct_dense_flow_voxel_torch(dense * t_scale, self.time_bin, self.flow_interpolation,
+                                                 t0_location=self.t0_flow_location) / t_scale
+        return voxel.cpu().numpy()
+
+    # -- what main.py calls on a solver besides optimize(): metrics and (optional) pictures ---------------------------------------
+    # (src/solver/base.py:230-250, 272-420, 543-660 and their overrides in patch_contrast_pyramid.py:518-660.)  The arithmetic of the
+    # metrics is the library's (Warp / EventImageConverter / costs over the HIP kernels) plus host NumPy for the end-point errors;
+    # the pictures are drawn by whatever `visualize_module` the caller passed -- without one every visualize_* returns at once.
+    @property
+    def motion_model_for_dense_warp(self) -> str:
+        return "dense-flow-voxel" if self.is_time_aware else "dense-flow"
+
+    @property
+    def warper(self):
+        if self._warper is None:
+            from ..warp import Warp
+
+            self._warper = Warp(self.image_shape, calculate_feature=True, normalize_t=self.normalize_t_in_batch, calib_param=self.calib_param)
+        return self._warper
+
+    @property
+    def imager(self):
+        if self._imager is None:
+            from ..event_image_converter import EventImageConverter
+
+            self._imager = EventImageConverter(self.image_shape, outer_padding=self.padding)
+        return self._imager
+
+    def get_original_flow_from_time_aware_flow_voxel(self, flow_voxel: np.ndarray) -> np.ndarray:
+        """[(b,) time_bin, 2, H, W] -> the slice the flow was given at (src/solver/base.py:230-250)."""
+        if flow_voxel.ndim == 4:
+            flow_voxel = flow_voxel[None]
+        if self.t0_flow_location == "first":
+            orig_ind = 0
+        elif self.t0_flow_location == "middle":
+            orig_ind = flow_voxel.shape[1] // 2
+        else:
+            raise NotImplementedError(f"t0_flow_location {self.t0_flow_location}")
+        return np.squeeze(flow_voxel[:, orig_ind])
+
+    def create_clipped_iwe_for_visualization(self, events: np.ndarray, max_scale=50) -> np.ndarray:
+        """src/solver/base.py:272-291: un-blurred IWE as an inverted 8-bit picture, padding cut off."""
+        assert events.shape[-1] <= 4, "this function is for events"
+        if hasattr(events, "detach"):
+            events = events.clone().detach().cpu().numpy()
+        im = self.imager.create_image_from_events_numpy(events, method=self.iwe_config["method"], sigma=0)
+        clipped_iwe = 255 - np.clip(max_scale * im, 0, 255).astype(np.uint8)
+        if self.padding > 0:
+            clipped_iwe = clipped_iwe[self.padding: -self.padding, self.padding: -self.padding]
+        return clipped_iwe
+
+    @staticmethod
+    def _batch_t_scale(events: np.ndarray) -> float:
+        return float(np.max(events[:, 2]) - np.min(events[:, 2]))
+
+    def visualize_one_batch_warp(self, events: np.ndarray, warp: Optional[dict] = None):
+        """patch_contrast_pyramid.py:518-536."""
+        if self.visualizer is None:
+            return
+        flow = None
+        if warp is not None:
+            flow = self.motion_to_dense_flow(warp)
+            if self.normalize_t_in_batch:
+                flow = flow * self._batch_t_scale(events)
+            events, _ = self.warper.warp_event(events, flow, self.motion_model_for_dense_warp)
+            if self.is_time_aware:
+                flow = self.get_original_flow_from_time_aware_flow_voxel(flow)
+        clipped_iwe = self.create_clipped_iwe_for_visualization(events, max_scale=self.iwe_visualize_max_scale)
+        self.visualizer.visualize_image(clipped_iwe)
+        if warp is not None:
+            self.visualizer.visualize_optical_flow_on_event_mask(flow, events)
+            self.visualizer.visualize_overlay_optical_flow_on_event(flow, clipped_iwe)
+
+    def visualize_one_batch_warp_gt(self, events: np.ndarray, gt_warp: np.ndarray, motion_model: str = "dense-flow"):
+        """src/solver/base.py:313-330; gt_warp [H, W, 2] for "dense-flow"."""
+        if self.visualizer is None:
+            return
+        if motion_model == "dense-flow":
+            gt_warp = np.transpose(gt_warp, (2, 0, 1))
+        events, _ = self.warper.warp_event(events, gt_warp, motion_model=motion_model)
+        clipped_iwe = self.create_clipped_iwe_for_visualization(events, max_scale=self.iwe_visualize_max_scale)
+        self.visualizer.visualize_image(clipped_iwe)
+        if motion_model == "dense-flow":
+            self.visualizer.visualize_overlay_optical_flow_on_event(gt_warp, clipped_iwe)
+
+    def visualize_original_sequential(self, events: np.ndarray):
+        """src/solver/base.py:332-341."""
+        if self.visualizer is None:
+            return
+        clipped_iwe = self.create_clipped_iwe_for_visualization(events, max_scale=self.iwe_visualize_max_scale)
+        self.visualizer.visualize_image(clipped_iwe, file_prefix="original")
+
+    def visualize_pred_sequential(self, events: np.ndarray, warp: dict):
+        """patch_contrast_pyramid.py:538-558 (warped to the MIDDLE of the batch, as the reference's override does)."""
+        if self.visualizer is None:
+            return
+        t_scale = self._batch_t_scale(events) if self.normalize_t_in_batch else 1.0
+        flow = self.motion_to_dense_flow(warp, t_scale) * t_scale
+        events, _ = self.warper.warp_event(events, flow, self.motion_model_for_dense_warp, direction="middle")
+        clipped_iwe = self.create_clipped_iwe_for_visualization(events, max_scale=self.iwe_visualize_max_scale)
+        if self.is_time_aware:
+            flow = self.get_original_flow_from_time_aware_flow_voxel(flow)
+        self.visualizer.visualize_image(clipped_iwe, file_prefix="pred_warp")
+        self.visualizer.visualize_optical_flow_on_event_mask(flow, events, file_prefix="pred_masked")
+
+    def visualize_gt_sequential(self, events: np.ndarray, gt_warp: np.ndarray, gt_type: str = "flow"):
+        """src/solver/base.py:385-420; gt_warp [H, W, 2] displacement."""
+        if self.visualizer is None:
+            return
+        if gt_type != "flow":
+            raise NotImplementedError("the patch solver's ground truth is a flow")
+        gt_flow = np.transpose(gt_warp, (2, 0, 1))
+        events, _ = self.warper.warp_event(events, gt_flow, "dense-flow", direction="first")
+        clipped_iwe = self.create_clipped_iwe_for_visualization(events, max_scale=self.iwe_visualize_max_scale)
+        self.visualizer.visualize_image(clipped_iwe, file_prefix="gt_warp")
+        self.visualizer.visualize_optical_flow(gt_flow[0], gt_flow[1], visualize_color_wheel=False, file_prefix="gt_flow")
+
+    def calculate_flow_error(self, motion: dict, gt_flow: np.ndarray, timescale: float = 1.0,
+                             events: Optional[np.ndarray] = None) -> dict:
+        """patch_contrast_pyramid.py:560-599: EPE / nPE / AE of the predicted displacement against gt_flow [H, W, 2] (masked by
+        the pixels that saw an event when `events` is given), plus the flow-warp-loss ratios of calculate_fwl."""
+        gt_flow = np.transpose(gt_flow, (2, 0, 1))  # [2, H, W]
+        pred_flow = self.motion_to_dense_flow(motion, timescale) * timescale
+        if self.is_time_aware:
+            pred_flow = self.get_original_flow_from_time_aware_flow_voxel(pred_flow)
+        pred_flow = pred_flow[None]
+        if events is not None:
+            event_mask = self.imager.create_eventmask(events)
+            if self.padding:
+                event_mask = event_mask[..., self.padding: -self.padding, self.padding: -self.padding]
+            fwl = self.calculate_fwl(motion, gt_flow, timescale, events)
+        else:
+            event_mask, fwl = None, {}
+        flow_error = calculate_flow_error_numpy(gt_flow[None], pred_flow, event_mask=event_mask)
+        flow_error.update(fwl)
+        logger.info(f"{flow_error = } for time period {timescale} sec.")
+        return flow_error
+
+    def calculate_fwl(self, motion: dict, gt_flow: np.ndarray, timescale: float, events: np.ndarray) -> dict:
+        """FWL (Stoffregen 2020) as the reference reports it, Var(IWE_orig) / Var(IWE): below 1 = sharper than the un-warped image
+        (patch_contrast_pyramid.py:601-629).  gt_flow [2, H, W] displacement over the batch."""
+        from .. import costs
+        from ..warp import Warp
+
+        orig_iwe = self.imager.create_iwe(events)
+        gt_warper = Warp(self.image_shape, normalize_t=True)
+        gt_warp, _ = gt_warper.warp_event(events, gt_flow, "dense-flow")
+        gt_iwe = self.imager.create_iwe(gt_warp)
+        gt_fwl = costs.NormalizedImageVariance().calculate({"orig_iwe": orig_iwe, "iwe": gt_iwe, "omit_boundary": False})
+        fwl = {"GT_FWL": gt_fwl}
+        fwl.update(self.calculate_fwl_pred(motion, events, timescale))
+        return fwl
+
+    def calculate_fwl_pred(self, motion: dict, events: np.ndarray, timescale: float = 1.0) -> dict:
+        """patch_contrast_pyramid.py:631-660."""
+        from .. import costs
+
+        orig_iwe = self.imager.create_iwe(events)
+        pred_flow = self.motion_to_dense_flow(motion, timescale) * timescale
+        pred_warp, _ = self.warper.warp_event(events, pred_flow, self.motion_model_for_dense_warp)
+        pred_iwe = self.imager.create_iwe(pred_warp)
+        pred_fwl = costs.NormalizedImageVariance().calculate({"orig_iwe": orig_iwe, "iwe": pred_iwe, "omit_boundary": False})
+        return {"PRED_FWL": pred_fwl}
+
+    def save_flow_error_as_text(self, nth_frame: int, flow_error_dict: dict, fname: str = "flow_error_per_frame.txt"):
+        """src/solver/base.py:651-660: one line per frame appended to <visualizer.save_dir>/<fname> (the working directory
+        without a visualizer)."""
+        save_file_name = os.path.join(self.visualizer.save_dir, fname) if self.visualizer is not None else fname
+        with open(save_file_name, "a") as f:
+            f.write(f"frame {nth_frame}::" + str(flow_error_dict) + "\n")
+
+
+def calculate_flow_error_numpy(flow_gt: np.ndarray, flow_pred: np.ndarray, event_mask: Optional[np.ndarray] = None) -> dict:
+    """End-point and angular errors of src/utils/flow_utils.py:705-758.  flow_gt / flow_pred [B, 2, H, W], event_mask [B, 1, H, W].
+    Only pixels whose ground truth is finite and non-zero in both components count (and, with a mask, saw an event); n_points carries
+    the reference's + 1e-5."""
+    assert flow_gt.ndim == flow_pred.ndim == 4
+    finite = ~np.isinf(flow_gt[:, [0]]) & ~np.isinf(flow_gt[:, [1]])
+    moving = (np.abs(flow_gt[:, [0]]) > 0) & (np.abs(flow_gt[:, [1]]) > 0)
+    total_mask = finite & moving
+    if event_mask is not None:
+        total_mask = np.logical_and(event_mask, total_mask)
+    with np.errstate(invalid="ignore"):  # inf * False
+        gt_masked = flow_gt * total_mask
+    pred_masked = flow_pred * total_mask
+    n_points = np.sum(total_mask, axis=(1, 2, 3)) + 1e-5
+    errors = {}
+    epe = np.linalg.norm(gt_masked - pred_masked, axis=1)
+    errors["EPE"] = np.mean(np.sum(epe, axis=(1, 2)) / n_points)
+    for k in (1, 2, 3, 5, 10, 20):
+        errors[f"{k}PE"] = np.mean(np.sum(epe > k, axis=(1, 2)) / n_points)
+    u, v = pred_masked[:, 0], pred_masked[:, 1]
+    u_gt, v_gt = gt_masked[:, 0], gt_masked[:, 1]
+    cosine = (1.0 + u * u_gt + v * v_gt) / (np.sqrt(1 + u * u + v * v) * np.sqrt(1 + u_gt * u_gt + v_gt * v_gt))
+    errors["AE"] = np.mean(np.sum(np.arccos(cosine), axis=(1, 2)) / n_points)
+    return errors

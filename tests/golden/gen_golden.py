@@ -880,6 +880,68 @@ def gen_global_best():
     save("global_best", **out)
 
 
+def gen_flow_error():
+    """What main.py asks of a solver after optimize() (main.py:100-103, 186-189): calculate_flow_error of the reference's pyramid solver
+    (src/solver/patch_contrast_pyramid.py:560-660: EPE / nPE / AE through utils.calculate_flow_error_numpy, GT_FWL / PRED_FWL through
+    imager.create_iwe + Warp + NormalizedImageVariance, numpy branch) for a plain and a time-aware (Burgers) solver, with and without
+    the event mask -> flow_error.npz"""
+    rng = np.random.default_rng(SEED + 12)
+    H, W = 68, 90
+    period = 0.05
+    # shim (4), this fixture only: the numpy branch of the patch interpolation calls cv2.resize(src, None, None, fx, fy, INTER_LINEAR)
+    # (patch_contrast_base.py:438-453), absent here like cv2.Sobel -> half-pixel-centre bilinear up-sampling = shim (2)'s arithmetic
+    import cv2
+
+    def _cv2_resize(src_img, dsize, dst=None, fx=0, fy=0, interpolation=1):
+        assert dsize is None and interpolation == cv2.INTER_LINEAR
+        t = torch.from_numpy(np.ascontiguousarray(src_img))[None, None]
+        size = [int(round(src_img.shape[0] * fy)), int(round(src_img.shape[1] * fx))]
+        return torch.nn.functional.interpolate(t, size=size, mode="bilinear", align_corners=False)[0, 0].numpy()
+
+    cv2.resize = _cv2_resize
+
+    def flow_fn(cx, cy):
+        return 6.0 + 4.0 * cx / H - 2.0 * cy / W, -5.0 + 3.0 * cy / W + 2.0 * cx / H
+
+    ev = _moving_dot_events(12000, H, W, flow_fn, rng, n_dots=120, period=period)
+    xs, ys = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    gx, gy = flow_fn(xs, ys)
+    gt_flow = np.stack([gx, gy], axis=-1)  # [H, W, 2] displacement over the batch (MVSEC convention)
+    gt_flow[:5, :7] = 0.0        # invalid ground truth (zeros) is excluded by the metric
+    gt_flow_inf = gt_flow.copy()  # ... infinities are meant to be, but `flow_gt * total_mask` turns them into NaN (inf * False): recorded as it is
+    gt_flow_inf[-3:, -4:] = np.inf
+    out = {"events": ev, "gt_flow": gt_flow, "image_size": np.array([H, W]), "timescale": np.array(period), "seed": np.array(SEED + 12)}
+    for tag, time_aware in (("plain", False), ("burgers", True)):
+        slv = _ref_pyramid_solver(H, W, time_aware, scale=3)
+        s = slv.patch_scales - 1
+        slv.overload_patch_configuration(s)
+        slv.current_scale = s
+        ph, pw = slv.patch_image_size
+        # motion in pixel / second; the dense flow the solver builds from it is its negative (interpolate_dense_flow_from_patch_*)
+        motion = -np.stack([np.full((ph, pw), 7.0), np.full((ph, pw), -4.0)]) / period * (1.0 + 0.2 * rng.uniform(-1, 1, (2, ph, pw)))
+        best = {s: motion}
+        with_mask = slv.calculate_flow_error(best, gt_flow, timescale=period, events=ev)
+        without = slv.calculate_flow_error(best, gt_flow, timescale=period)
+        pred_only = slv.calculate_fwl_pred(best, ev, period)
+        if not time_aware:
+            with np.errstate(invalid="ignore"):
+                inf_case = slv.calculate_flow_error(best, gt_flow_inf, timescale=period)
+            out["gt_flow_inf"] = gt_flow_inf
+            for k, v in inf_case.items():
+                out[f"plain__inf__{k}"] = np.array(float(v))
+        out[tag + "__scale"] = np.array(s)
+        out[tag + "__motion"] = motion
+        out[tag + "__dense"] = np.asarray(slv.motion_to_dense_flow(best, period))  # [2,H,W] or [T,2,H,W]
+        for k, v in with_mask.items():
+            out[f"{tag}__mask__{k}"] = np.array(float(v))
+        for k, v in without.items():
+            out[f"{tag}__nomask__{k}"] = np.array(float(v))
+        out[tag + "__fwl_pred_only"] = np.array(float(pred_only["PRED_FWL"]))
+        print(tag, {k: round(float(v), 5) for k, v in with_mask.items()})
+    out["extra_shim"] = np.array("cv2.resize(INTER_LINEAR) -> F.interpolate(bilinear, align_corners=False)")
+    save("flow_error", **out)
+
+
 def gen_core():
     torch.manual_seed(SEED)
     np.random.seed(SEED)
@@ -895,10 +957,10 @@ def gen_core():
 
 if __name__ == "__main__":
     # python tests/golden/gen_golden.py [core] [solver] [blur_numpy] [hvp_cases] [solver_hvp] [patch_search] [solver_optimize]
-    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized] [outside_sensor] [global_best]   (no argument = everything)
+    #                                    [solver_cfg1] [hvp_inv] [costs_batched] [solver_cfg1_variance] [cfg2_fp32] [warp_voxel_optimized] [outside_sensor] [global_best] [flow_error]   (no argument = everything)
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["core", "solver", "blur_numpy", "hvp_cases", "solver_hvp",
                                                                     "patch_search", "solver_optimize", "solver_cfg1", "hvp_inv", "costs_batched",
-                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized", "outside_sensor", "global_best"]
+                                                                    "solver_cfg1_variance", "cfg2_fp32", "warp_voxel_optimized", "outside_sensor", "global_best", "flow_error"]
     if "core" in which:
         gen_core()
     if "solver" in which:
@@ -929,3 +991,5 @@ if __name__ == "__main__":
         gen_outside_sensor()
     if "global_best" in which:
         gen_global_best()
+    if "flow_error" in which:
+        gen_flow_error()

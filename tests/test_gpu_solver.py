@@ -743,3 +743,48 @@ def test_patch_search_walks_slab_order(golden):
         loss1, gm1, count1 = h.patch_search(boxes, tuple(g["s2__patch_size"]), cand, 1.0)
         assert torch.equal(count0, count1)
         assert rel_max(gm1.cpu().numpy(), gm0.cpu().numpy()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the rest of the class contract main.py drives -- metrics and pictures -- on the real class.
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,time_aware", [("plain", False), ("burgers", True)])
+def test_flow_error_and_fwl_of_the_solver_class_against_the_reference(golden, tag, time_aware, tmp_path):
+    """calculate_flow_error / calculate_fwl / calculate_fwl_pred (src/solver/patch_contrast_pyramid.py:560-660) through the library:
+    patch -> dense flow [-> Burgers voxel], Warp, EventImageConverter (numpy branch: eps 1e-8, scipy-style blur) and
+    NormalizedImageVariance are all HIP kernels; tests/golden/flow_error.npz = the reference's own dictionaries for this scene."""
+    from test_solver_contract import METRICS, OPT_CFG, Recorder, solver_config
+
+    g = golden("flow_error")
+    H, W = (int(v) for v in g["image_size"])
+    period = float(g["timescale"])
+    events, gt_flow = g["events"], g["gt_flow"]
+    s = int(g[tag + "__scale"])
+    best = {s: g[tag + "__motion"]}
+    viz = Recorder(str(tmp_path))
+    solv = E.solver.collections["pyramidal_patch_contrast_maximization"]((H, W), {}, solver_config(time_aware), OPT_CFG, {}, viz)
+    dense = solv.motion_to_dense_flow(best, period)
+    assert dense.shape == g[tag + "__dense"].shape
+    assert rel_max(dense, g[tag + "__dense"]) <= TOL
+    err = solv.calculate_flow_error(best, gt_flow, period, events)
+    worst = max(abs(err[k] - float(g[f"{tag}__mask__{k}"])) / max(abs(float(g[f"{tag}__mask__{k}"])), 1e-3) for k in METRICS + ["GT_FWL", "PRED_FWL"])
+    print(f"[solver] {tag}: flow error / FWL against the reference, worst relative deviation {worst:.2e}: "
+          f"EPE {err['EPE']:.5f} AE {err['AE']:.5f} GT_FWL {err['GT_FWL']:.5f} PRED_FWL {err['PRED_FWL']:.5f}")
+    for k in METRICS + ["GT_FWL", "PRED_FWL"]:
+        assert err[k] == pytest.approx(float(g[f"{tag}__mask__{k}"]), rel=TOL, abs=1e-3 * TOL), k  # (the nPE are counts / n: exact)
+    assert solv.calculate_fwl_pred(best, events, period)["PRED_FWL"] == pytest.approx(float(g[tag + "__fwl_pred_only"]), rel=TOL)
+    nomask = solv.calculate_flow_error(best, gt_flow, period)
+    for k in METRICS:
+        assert nomask[k] == pytest.approx(float(g[f"{tag}__nomask__{k}"]), rel=TOL, abs=1e-3 * TOL), k
+    # the pictures: every driver call reaches the visualizer with real arrays behind it
+    solv.visualize_one_batch_warp(events)
+    solv.visualize_one_batch_warp(events, best)
+    solv.visualize_one_batch_warp_gt(events, gt_flow)
+    solv.visualize_original_sequential(events)
+    solv.visualize_pred_sequential(events, best)
+    solv.visualize_gt_sequential(events, gt_flow)
+    assert [c[0] for c in viz.calls].count("visualize_image") == 6
+    solv.save_flow_error_as_text(3, err, "flow_error_per_frame_with_mask.txt")
+    assert open(tmp_path / "flow_error_per_frame_with_mask.txt").read().startswith("frame 3::{")
+    iwe = solv.create_clipped_iwe_for_visualization(events)
+    assert iwe.dtype == np.uint8 and iwe.shape == (H, W) and iwe.min() < 255
