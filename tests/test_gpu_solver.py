@@ -348,6 +348,9 @@ def test_pyramid_solver_end_to_end(time_aware):
     # the reference's feedback dict: finest ... coarsest - 1 (update_coarse_from_fine, patch_contrast_pyramid.py:205-222)
     assert sorted(best) == [0, 1, 2, 3] and best[3].shape == (2, 8, 8) and best[1].shape == (2, 2, 2)
     flow = slv.motion_to_dense_flow(best) * t_scale  # pixel displacement over the batch
+    if time_aware:  # the flow voxel [time_bin, 2, H, W] (patch_contrast_pyramid.py:486-516): the slice the motion was given at
+        assert flow.shape == (10, 2, H, W)
+        flow = slv.get_original_flow_from_time_aware_flow_voxel(flow)
     mask = np.zeros((H, W), bool)
     mask[x.astype(int), y.astype(int)] = True
     mask[:4] = mask[-4:] = False
@@ -503,13 +506,17 @@ def test_pyramid_solver_reused_across_frames(time_aware):
         best_fresh = fresh.optimize(ev)
         handle_ids.add(id(slv._handle))
         objective_ids.add(tuple(id(slv._objectives[s]) for s in sorted(slv._objectives)))
-        flow = slv.motion_to_dense_flow(best) * t_scale
+        def displacement(s, b):  # [2, H, W] over the batch (time-aware: the voxel's slice at the original time)
+            f = s.motion_to_dense_flow(b) * t_scale
+            return s.get_original_flow_from_time_aware_flow_voxel(f) if time_aware else f
+
+        flow = displacement(slv, best)
         mask = np.zeros((H, W), bool)
         mask[x.astype(int), y.astype(int)] = True
         mask[:4] = mask[-4:] = False
         mask[:, :8] = mask[:, -8:] = False
         aee = np.sqrt(((flow - V) ** 2).sum(0))[mask].mean()
-        aee_fresh = np.sqrt(((fresh.motion_to_dense_flow(best_fresh) * t_scale - V) ** 2).sum(0))[mask].mean()
+        aee_fresh = np.sqrt(((displacement(fresh, best_fresh) - V) ** 2).sum(0))[mask].mean()
         aee0 = np.sqrt((V ** 2).sum(0))[mask].mean()
         assert aee < aee0 and aee <= aee_fresh + 0.15 * aee0, (frame, aee, aee_fresh, aee0)
     assert len(handle_ids) == 1 and len(objective_ids) == 1

@@ -73,6 +73,8 @@ for time_aware, grid in ((False, None), (False, 0), (False, 16), (True, None), (
     njev = sum(getattr(r, "njev", 0) for _, r in slv.history)
     nhev = sum(getattr(r, "nhev", 0) for _, r in slv.history)
     flow = slv.motion_to_dense_flow(best) * t_scale
+    if flow.ndim == 4:  # time-aware: the voxel's slice at the original time
+        flow = slv.get_original_flow_from_time_aware_flow_voxel(flow)
     aee = np.sqrt(((flow - V) ** 2).sum(0))[mask].mean()
     aee0 = np.sqrt((V ** 2).sum(0))[mask].mean()
     n_pairs = sum(c.shape[0] * c.shape[1] for _, c, _, _ in slv.search_history)
