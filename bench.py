@@ -482,9 +482,30 @@ def comm_probe_run(dev, world, rank, args, reps=50):
     import event_based_optical_flow_amd as E
     from event_based_optical_flow_amd.distributed import TimeSlicedObjective
 
-    handle = E.CMaxHandle((64, 64))
-    sliced = TimeSlicedObjective(handle, in_library=not args.torch_collectives)
-    in_lib = sliced.collectives.startswith("in-library")
+    # The probe is collective: every rank must take the same path.  Set-up (handle, communicator, the largest buffer) happens under a
+    # per-rank try, then the ranks AGREE on its success (one MIN all-reduce) before any barrier / all-reduce of the timed loops -- a
+    # rank that failed alone would otherwise leave the others blocked in dist.barrier.
+    handle = sliced = None
+    err = ""
+    try:
+        handle = E.CMaxHandle((64, 64))
+        sliced = TimeSlicedObjective(handle, in_library=not args.torch_collectives)
+        in_lib = sliced.collectives.startswith("in-library")
+        probe = torch.zeros(2 * 720 * 1280, dtype=torch.float32, device=dev)
+        if in_lib:
+            handle.comm_allreduce  # (attribute exists: the library path is available on this rank)
+        del probe
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"[:200]
+    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1.0:
+        if handle is not None:
+            handle.close()
+        return {"error": "set-up failed on at least one rank" + (f" (this rank: {err})" if err else ""), "n_ranks": world}
+    flag = torch.tensor([1.0 if in_lib else 0.0], dtype=torch.float64, device=dev)  # ... and on WHICH collectives (all in-library or none)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    in_lib = in_lib and flag.item() >= 1.0
     sizes = {"grad_2dof_16B": (2, torch.float64), "grad_patch_4KB": (512, torch.float64),
              "cfg2_single_exchange": (3 * 260 * 346 + 260 + 346, torch.float32), "cfg5_C1_image": (720 * 1280, torch.float32),
              "cfg5_C2_flow_gradient": (2 * 720 * 1280, torch.float32)}
@@ -810,7 +831,8 @@ def main():
         # keeps the last 8 KB of stdout, so the rows for cfg3 / cfg4 / cfg5 / cfg5_strong / hbm never reached BENCH_r04.json).
         vpath = args.verbose_out or os.path.join(ROOT, "gpurun_out", "bench_verbose_%s_n%d.json" % (args.workload, world))
         try:
-            os.makedirs(os.path.dirname(vpath), exist_ok=True)
+            if os.path.dirname(vpath):  # (a bare file name has no directory part: makedirs('') raises)
+                os.makedirs(os.path.dirname(vpath), exist_ok=True)
             with open(vpath, "w") as f:
                 json.dump(out, f)
         except OSError as e:

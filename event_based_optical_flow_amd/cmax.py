@@ -132,7 +132,17 @@ class CMaxHandle:
                                         F._stream()))
         self.time_bin = int(time_bin)
         self.time_slabs = 0
-        dropped = self.batch_info()["dropped"] if on_dropped != "ignore" else 0
+        info = self.batch_info() if on_dropped != "ignore" else {"dropped": 0, "outside": 0}
+        dropped = info["dropped"]
+        if info["outside"]:
+            # said HERE, at the batch, not at the first dense evaluation behind the sort: keeping off-sensor events is the
+            # default since round 5 and only the 2-DoF model is defined for them
+            msg = (f"cmax_set_events kept {info['outside']} of {ev.shape[0]} events whose source pixel lies off the "
+                   f"{self.image_size[0]} x {self.image_size[1]} sensor (the reference's 2-DoF warp has no bounds test, src/warp.py:506-515); "
+                   "dense / voxel objectives and the patch search refuse such a batch -- set_keep_outside(False) before set_events drops them")
+            if on_dropped == "raise":
+                raise ValueError(msg)
+            logger.warning(msg)
         if dropped and on_dropped == "raise":
             raise ValueError(f"cmax_set_events dropped {dropped} of {ev.shape[0]} events whose source pixel is outside the "
                              f"{self.image_size[0]} x {self.image_size[1]} sensor (or NaN); use the leaf operators (Warp + "

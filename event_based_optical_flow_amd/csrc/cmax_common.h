@@ -78,6 +78,7 @@ __attribute__((visibility("hidden"))) int objective_dist_local_grad(cmax_handle_
 __attribute__((visibility("hidden"))) int objective_hvp_dist_local(cmax_handle_t h, const cmax_objective_t *d, const float *motion,
                                                                 const float *tangent, void *hv, hipStream_t s);
 __attribute__((visibility("hidden"))) int handle_allreduce_sum(cmax_handle_t h, void *buf, size_t count, bool f64, hipStream_t s);
+__attribute__((visibility("hidden"))) int handle_allreduce_sum_with_scalars(cmax_handle_t h, void *buf, size_t count, bool f64, double *scalars, int n_scalars, hipStream_t s);
 
 // ---- wave / block reductions (64-wide) -------------------------------------------------------
 // DPP on the VALU instead of ds_bpermute shuffles (~16 cycles each on gfx950): 4 row shifts, then lane 15 of

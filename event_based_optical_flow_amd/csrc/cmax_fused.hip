@@ -2496,7 +2496,10 @@ static int build_segments(cmax_handle_s *h, int stride, hipStream_t s, BatchRead
     // CMAX_COMPACT=0 switches it off (A/B runs).
     static const int compact_env = getenv("CMAX_COMPACT") ? atoi(getenv("CMAX_COMPACT")) : 1;
     h->compact = false;
-    if (h->big && T == 1 && !slab && h->n_time_bin == 0 && h->nseg > 0 && compact_env != 0) {
+    // ... and long runs only: the dense K3 of a short-run batch that is not `owned` is kGradStrided, whose slot layout reads the 8-byte
+    // events -- K1 must then warp with the same fp32 time (K3 follows K1's cells and windows without tests), so such a handle gets no compact
+    // copy at all (big segments + short runs = a sparse batch on a very large sensor, or CMAX_BIG_SEG=1).
+    if (h->big && T == 1 && !slab && h->n_time_bin == 0 && h->nseg > 0 && compact_env != 0 && h->long_runs) {
         if (h->nseg > h->cev_cap) {
             dev_free(&h->cev);
             h->cev_cap = 0;
@@ -3092,17 +3095,46 @@ static int c2_prepare_bands(cmax_handle_s *h, int bands) {
     }
     return 0;
 }
-// band b's rows of both channels, all-reduced on the second stream once `s` has passed this point
-static int c2_exchange_band(cmax_handle_s *h, cmax::Comm *c2_comm, float *grad, int b, int bands, hipStream_t s) {
+// RANK-CONSISTENT SCALARS (round 6).  After C1 every rank evaluates the contrast on the same reduced image, but with
+// fp64 atomics in its own order: result[8] (loss and statistics) agrees across ranks to ~1e-16 relative, not bit for bit -- and every
+// rank runs its own copy of the optimiser (src/solver/scipy_autograd/scipy_minimize.py:100-117), where ONE differing Wolfe / Armijo
+// comparison means different call sequences, mismatched collectives, a hang.  The gradient is identical by construction (it is
+// all-reduced); the scalars are made so by the same exchange: every rank but 0 zeroes its result[8] behind its last writer and the
+// eight doubles ride in the gradient's (grouped) all-reduce -- x + 0 + ... + 0 is exact, so all ranks leave with rank 0's bits.  A
+// value-only evaluation gets the 64-byte exchange on its own.  A 1-rank communicator runs the same sequence.
+static int result_zero_unless_rank0(cmax::Comm *comm, double *result, hipStream_t s) {
+    if (comm && result && comm_rank(comm) != 0) CMAX_CHECK_HIP(hipMemsetAsync(result, 0, 8 * sizeof(double), s));
+    return 0;
+}
+static int result_exchange_alone(cmax::Comm *comm, double *result, hipStream_t s) {
+    int rc = result_zero_unless_rank0(comm, result, s);
+    return rc ? rc : comm_allreduce(comm, result, 8, kCommF64, kCommSum, s);
+}
+// the gradient's all-reduce with result[8] riding along (one grouped RCCL call)
+static int grad_and_result_exchange(cmax::Comm *comm, void *grad, size_t gcount, CommType gtype, double *result, hipStream_t s) {
+    int rc = result_zero_unless_rank0(comm, result, s);
+    if (rc) return rc;
+    void *bufs[2] = {grad, result};
+    const size_t counts[2] = {gcount, 8};
+    const CommType types[2] = {gtype, kCommF64};
+    return comm_allreduce_group(comm, bufs, counts, types, result ? 2 : 1, kCommSum, s);
+}
+
+// band b's rows of both channels, all-reduced on the second stream once `s` has passed this point (band 0 carries result[8], see above)
+static int c2_exchange_band(cmax_handle_s *h, cmax::Comm *c2_comm, float *grad, int b, int bands, hipStream_t s, double *result = nullptr) {
     const int tr0 = (int)((int64_t)h->ntr * b / bands), tr1 = (int)((int64_t)h->ntr * (b + 1) / bands);
     const int64_t hw = (int64_t)h->H * h->W;
+    if (b == 0 && result) {
+        int rc = result_zero_unless_rank0(c2_comm, result, s);
+        if (rc) return rc;
+    }
     CMAX_CHECK_HIP(hipEventRecord(h->band_ev[b], s));
     CMAX_CHECK_HIP(hipStreamWaitEvent(h->comm_stream, h->band_ev[b], 0));
     const int r0 = tr0 * kTile, r1 = std::min(tr1 * kTile, h->H);
-    void *bufs[2] = {grad + (int64_t)r0 * h->W, grad + hw + (int64_t)r0 * h->W};
-    const size_t counts[2] = {(size_t)(r1 - r0) * h->W, (size_t)(r1 - r0) * h->W};
-    const CommType types[2] = {kCommF32, kCommF32};
-    return comm_allreduce_group(c2_comm, bufs, counts, types, 2, kCommSum, h->comm_stream);
+    void *bufs[3] = {grad + (int64_t)r0 * h->W, grad + hw + (int64_t)r0 * h->W, result};
+    const size_t counts[3] = {(size_t)(r1 - r0) * h->W, (size_t)(r1 - r0) * h->W, 8};
+    const CommType types[3] = {kCommF32, kCommF32, kCommF64};
+    return comm_allreduce_group(c2_comm, bufs, counts, types, (b == 0 && result) ? 3 : 2, kCommSum, h->comm_stream);
 }
 // the reduced gradient back to the caller's stream
 static int c2_join_bands(cmax_handle_s *h, int bands, hipStream_t s) {
@@ -3111,9 +3143,9 @@ static int c2_join_bands(cmax_handle_s *h, int bands, hipStream_t s) {
     return 0;
 }
 // every band behind a gradient that is already complete on this rank
-static int c2_exchange_all_bands(cmax_handle_s *h, cmax::Comm *c2_comm, float *grad, int bands, hipStream_t s) {
+static int c2_exchange_all_bands(cmax_handle_s *h, cmax::Comm *c2_comm, float *grad, int bands, hipStream_t s, double *result) {
     int rc = c2_prepare_bands(h, bands);
-    for (int b = 0; b < bands && !rc; ++b) rc = c2_exchange_band(h, c2_comm, grad, b, bands, s);
+    for (int b = 0; b < bands && !rc; ++b) rc = c2_exchange_band(h, c2_comm, grad, b, bands, s, result);
     return rc ? rc : c2_join_bands(h, bands, s);
 }
 
@@ -3232,7 +3264,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
     if (h->n == 0) {  // this rank holds no events of the batch
         CMAX_CHECK_HIP(hipMemsetAsync(grad, 0, gbytes, s));
         if (bands > 1) {  // ... and still takes part in every band's exchange
-            rc = c2_exchange_all_bands(h, c2_comm, (float *)grad, bands, s);
+            rc = c2_exchange_all_bands(h, c2_comm, (float *)grad, bands, s, result);
             if (rc) return rc;
             if (c2_done) *c2_done = true;
         }
@@ -3369,7 +3401,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
             rb.shifts += (int64_t)s0 * (h->big ? 512 : (h->mid ? 384 : 256));
             if (s1 > s0) launch_grad<CMAX_MODEL_DENSE>(h, ev, wp, rb, d->n_ref, fold, op, nullptr, (float *)grad, b == 0 ? res : nullptr, owned, s, s0, s1 - s0);
             CMAX_CHECK_LAUNCH();
-            rc = c2_exchange_band(h, c2_comm, (float *)grad, b, bands, s);
+            rc = c2_exchange_band(h, c2_comm, (float *)grad, b, bands, s, result);
             if (rc) return rc;
         }
         rc = c2_join_bands(h, bands, s);
@@ -3392,7 +3424,7 @@ static int objective_finish(cmax_handle_t h, const cmax_objective_t *d, const fl
         CMAX_CHECK_LAUNCH();
     }
     if (bands > 1) {  // this rank's work list does not allow K3 in bands (or the mode is deterministic): the same exchanges behind one launch
-        rc = c2_exchange_all_bands(h, c2_comm, (float *)grad, bands, s);
+        rc = c2_exchange_all_bands(h, c2_comm, (float *)grad, bands, s, result);
         if (rc) return rc;
         if (c2_done) *c2_done = true;
         return 0;
@@ -3433,6 +3465,11 @@ static bool tan2_applicable(const cmax_handle_s *h, const cmax_objective_t *d, c
     static const int force = getenv("CMAX_TAN2") ? atoi(getenv("CMAX_TAN2")) : -1;  // tuning: 1 = also on one GPU, 0 = never
     if (force == 0 || h->deterministic || !grad) return false;
     if (d->model != CMAX_MODEL_2DOF || d->cost != CMAX_COST_VARIANCE || d->sigma > 0) return false;
+    // Rank-consistent scalars: behind the single exchange every rank finishes loss AND gradient on its own -- from the reduced planes in a
+    // fixed order (per-workgroup partials, one folding wave: bit-identical on every rank), but a NORMALISED variance also reads the
+    // un-warped image's cached statistics, which each rank summed with atomics in its own order.  Across real ranks that objective
+    // takes the two-exchange path, whose gradient is all-reduced and whose scalars ride along.
+    if (d->normalized && h->comm && comm_nranks(h->comm) > 1) return false;
     if (d->normalized && !(h->orig_valid && h->orig_sigma == d->sigma && h->orig_cost == d->cost && h->orig_omit == d->omit_boundary))
         return false;  // the first evaluation of a batch builds the un-warped image's statistics on the standard path
     return dist || force == 1;
@@ -3568,9 +3605,13 @@ static int objective_eval(cmax_handle_t h, const cmax_objective_t *d, const floa
     if (rc) return rc;
     h->zero_mask[h->cur_buf ^ 1] |= used;  // zeroed by this evaluation's k_stats launches
     h->cur_buf ^= 1;
-    if (dist && grad && !raw_out && !c2_done && !skip_c2) {  // C2
+    if (dist && grad && !raw_out && !c2_done && !skip_c2) {  // C2, result[8] riding along (rank-consistent scalars)
         ProfScope prof(h, kProfComm, s);
-        rc = comm_allreduce(comm, grad, (size_t)gcount, d->model == CMAX_MODEL_2DOF ? kCommF64 : kCommF32, kCommSum, s);
+        rc = grad_and_result_exchange(comm, grad, (size_t)gcount, d->model == CMAX_MODEL_2DOF ? kCommF64 : kCommF32, result, s);
+        if (rc) return rc;
+    } else if (dist && !grad && !raw_out && !skip_c2) {  // value only: the 64 bytes on their own
+        ProfScope prof(h, kProfComm, s);
+        rc = result_exchange_alone(comm, result, s);
         if (rc) return rc;
     }
     return 0;
@@ -4178,6 +4219,17 @@ int handle_allreduce_sum(cmax_handle_t h, void *buf, size_t count, bool f64, hip
     if (!h || !h->comm) return 0;
     ProfScope prof(h, kProfComm, s);
     return comm_allreduce(h->comm, buf, count, f64 ? kCommF64 : kCommF32, kCommSum, s);
+}
+// ... with `n_scalars` doubles that every rank computed redundantly (the per-term result[8] of the patch plan) made RANK 0'S on every
+// rank by the same grouped call (rank-consistent scalars, see result_zero_unless_rank0); buf may be null (value-only evaluation)
+int handle_allreduce_sum_with_scalars(cmax_handle_t h, void *buf, size_t count, bool f64, double *scalars, int n_scalars, hipStream_t s) {
+    if (!h || !h->comm) return 0;
+    ProfScope prof(h, kProfComm, s);
+    if (comm_rank(h->comm) != 0) CMAX_CHECK_HIP(hipMemsetAsync(scalars, 0, (size_t)n_scalars * sizeof(double), s));
+    void *bufs[2] = {scalars, buf};
+    const size_t counts[2] = {(size_t)n_scalars, count};
+    const CommType types[2] = {kCommF64, f64 ? kCommF64 : kCommF32};
+    return comm_allreduce_group(h->comm, bufs, counts, types, (buf && count) ? 2 : 1, kCommSum, s);
 }
 }  // namespace cmax
 

@@ -235,6 +235,14 @@ int plan_reduce_gx(cmax_patch_plan_s *p, const double *gx64, const float *gx32, 
     if (gx64) return handle_allreduce_sum(p->handle, const_cast<double *>(gx64), (size_t)p->nx, true, s);
     return handle_allreduce_sum(p->handle, const_cast<float *>(gx32), (size_t)p->nx, false, s);
 }
+// ... of an EVALUATION: the terms' result[8] ride along and leave as rank 0's on every rank (each rank summed its statistics in its own
+// order; replicated optimisers must see the same loss bit for bit).  Value-only evaluations exchange the scalars alone.
+int plan_reduce_gx_and_results(cmax_patch_plan_s *p, const double *gx64, const float *gx32, hipStream_t s) {
+    if (!handle_has_comm(p->handle)) return 0;
+    const int n_scalars = 8 * p->d.n_terms;
+    if (gx64) return handle_allreduce_sum_with_scalars(p->handle, const_cast<double *>(gx64), (size_t)p->nx, true, p->results, n_scalars, s);
+    return handle_allreduce_sum_with_scalars(p->handle, const_cast<float *>(gx32), gx32 ? (size_t)p->nx : 0, false, p->results, n_scalars, s);
+}
 
 // x (host) -> fp32 motion of the fused objective: flow [2,H,W] or voxel [T,2,H,W] in pixel per normalised time.
 // Leaves the fp64 flow (scaled) in flow64 and, when time-aware, the fp64 voxel in vox64.
@@ -323,11 +331,10 @@ int enqueue_evaluate(cmax_patch_plan_s *p, bool tv, bool want_grad, hipStream_t 
     const double *gx64 = nullptr;
     const float *gx32 = nullptr;
     double wscale = 1.0;
-    if (want_grad) {
-        rc = backward_motion(p, &gx64, &gx32, &wscale, s);
-        if (!rc) rc = plan_reduce_gx(p, gx64, gx32, s);
-        if (rc) return rc;
-    }
+    if (want_grad) rc = backward_motion(p, &gx64, &gx32, &wscale, s);
+    if (!rc && d.n_terms > 0) rc = plan_reduce_gx_and_results(p, gx64, gx32, s);
+    else if (!rc && want_grad) rc = plan_reduce_gx(p, gx64, gx32, s);
+    if (rc) return rc;
     FinalParams fp;
     fp.n_terms = d.n_terms;
     fp.flag_slot = 1 + (int)p->nx;

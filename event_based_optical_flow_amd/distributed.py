@@ -9,7 +9,8 @@ dL/dIWE.  Per objective evaluation there are exactly two exchange steps:
     C2  all-reduce(sum) of the gradient          double[2] | fp32 [2,H,W] | fp32 [T,2,H,W]
 
 Between them every rank redundantly evaluates the (image-space, microseconds) contrast on the
-reduced image, which avoids a broadcast.  Both collectives are enqueued BY THE LIBRARY, on the stream
+reduced image; its scalars (result[8]: loss, statistics) leave the evaluation as RANK 0'S BITS on every rank -- they ride in
+C2 (one grouped RCCL call; x + 0 + ... + 0 is exact), so replicated optimisers take identical decisions.  Both collectives are enqueued BY THE LIBRARY, on the stream
 of its kernels (cmax_comm_init + cmax_objective_dist: RCCL bound inside libcmax_hip.so): one ctypes
 call per evaluation, no Python between the phases.  torch.distributed only ships the RCCL rendezvous
 id once; if the library cannot bring up its communicator (no librccl), or for a `local` without one
@@ -101,6 +102,17 @@ class TimeSlicedObjective:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def _rank0_value(self, t: torch.Tensor):
+        """Scalars every rank computed redundantly on the reduced image (loss, statistics: fp64 sums in each rank's own order, equal
+        to ~1e-16, not bit for bit) become RANK 0'S on every rank.  Replicated optimisers -- every rank runs the same SciPy loop
+        (src/solver/scipy_autograd/scipy_minimize.py:100-117) -- must see identical values: one differing line-search comparison means
+        different call sequences and mismatched collectives.  (The library's own path lets result[8] ride in the gradient's all-reduce,
+        cmax_objective_dist; this fall-back spends a broadcast.)"""
+        if self.world_size > 1:
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(t, src=src, group=self.group)
+        return t
+
     def prepare(self, desc, motion, want_grad: bool = True):
         """(call, result, grad): `call()` = one evaluation of the whole batch with preallocated outputs (CMaxHandle.prepare);
         the torch-collectives fallback and stand-in locals get a closure over `evaluate` that copies into the same buffers."""
@@ -126,4 +138,5 @@ class TimeSlicedObjective:
         result, grad = self.local.objective_finish(desc, motion, images, want_grad)
         if grad is not None:
             self._all_reduce(grad)  # C2
+        self._rank0_value(result)  # rank-consistent scalars
         return result, grad

@@ -30,6 +30,7 @@ class _SlicedFusedFn(torch.autograd.Function):
         images = local.objective_vote(desc, motion)
         sliced._all_reduce(images)
         result, grad = local.objective_finish(desc, motion, images, want_grad=motion.requires_grad)
+        sliced._rank0_value(result)  # the term's scalars as rank 0 summed them, on every rank (TimeSlicedObjective._rank0_value)
         ctx.grad, ctx.mdtype = grad, motion.dtype
         return result[0].to(motion.dtype)
 

@@ -51,6 +51,11 @@ def grid_search_translation(handle: CMaxHandle, t_scale: float, field_x: Sequenc
     gx, gy = np.meshgrid(fx, fy, indexing="ij")
     cand = np.stack([gx.reshape(-1), gy.reshape(-1)], axis=1)
     loss = candidate_losses(handle, cand, t_scale, **cost_kwargs)
-    loss = np.where(np.isnan(loss), 0.0, loss)  # calculate_cost turns a NaN loss into 0.0 (patch_contrast_base.py:283-286)
-    best = int(np.argmin(loss))  # first occurrence, like the reference's `if loss < best_loss`
+    # A NaN candidate never wins: in initialize_guess_from_whole_image / _from_patch the loss is a torch tensor, calculate_cost's NaN -> 0.0
+    # applies to numpy losses only (patch_contrast_base.py:283-286), and `loss < best_loss` is False for a NaN -- the candidate is skipped;
+    # when every candidate is NaN the reference keeps its initial best_guess = zeros(2).  
+    ranked = np.where(np.isnan(loss), np.inf, loss)
+    if not np.isfinite(ranked).any():
+        return np.zeros(2), loss.reshape(len(fx), len(fy))
+    best = int(np.argmin(ranked))  # first occurrence, like the reference's `if loss < best_loss`
     return cand[best].copy(), loss.reshape(len(fx), len(fy))

@@ -24,8 +24,9 @@ from oracle import oracle as orc
 class OracleLocal:
     """Rank-local phases with the CMaxHandle interface, computed by the fp64 oracle."""
 
-    def __init__(self, image_size):
+    def __init__(self, image_size, loss_jitter=0.0):
         self.size = image_size
+        self.loss_jitter = loss_jitter  # relative perturbation of THIS rank's loss: the stand-in for fp64 atomics in another order
 
     def set_events(self, events, tmin, tmax, time_bin=0):
         self.ev = np.ascontiguousarray(events, dtype=np.float64)
@@ -74,7 +75,7 @@ class OracleLocal:
             model = "2d-translation" if desc.model == _lib.MODEL_2DOF else "dense-flow"
             grad = grad + orc.motion_grad(self.ev, motion, model, {"dt": dt}, gx, gy)
         res = torch.zeros(8, dtype=torch.float64)
-        res[0] = loss
+        res[0] = loss * (1.0 + self.loss_jitter)
         return res, torch.from_numpy(np.ascontiguousarray(grad))
 
 
@@ -138,6 +139,85 @@ def test_time_sliced_objective_world2(case):
     for rank, loss, grad in got:
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-11)
         np.testing.assert_allclose(grad, ref["grad"], rtol=1e-8, atol=1e-13 * max(1.0, np.abs(ref["grad"]).max()))
+
+
+class _SlicedLoss(torch.autograd.Function):
+    """loss(theta) of a TimeSlicedObjective as an autograd node: what TorchWrapper differentiates under scipy.optimize.minimize"""
+
+    @staticmethod
+    def forward(ctx, theta, obj, desc):
+        res, grad = obj.evaluate(desc, theta.detach())
+        ctx.grad = grad
+        return res[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ctx.grad * gout, None, None
+
+
+def _minimize_worker(rank, world, port, consistent, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from event_based_optical_flow_amd.solver.scipy_autograd import minimize
+
+        size = (24, 32)
+        ev = E.utils.generate_structured_events(3001, size[0], size[1], (6.0, -4.0), n_dots=40, seed=8)
+        lo, hi = time_slice_bounds(len(ev), world, rank)
+        # every rank's loss carries ITS OWN last-bit noise, like statistics summed with atomics in another order on every GPU
+        obj = TimeSlicedObjective(OracleLocal(size, loss_jitter=(3e-16, -5e-16)[rank]))
+        if not consistent:  # negative control: the evaluation as it was before round 6 (no rank-0 scalars)
+            obj._rank0_value = lambda t: t
+        obj.set_local_events(ev[lo:hi])
+        desc = E.make_descriptor("image_variance", "2d-translation", sigma=0.0)
+        losses = []
+
+        def fun(theta):
+            loss = _SlicedLoss.apply(theta, obj, desc)
+            losses.append(float(loss))
+            return loss
+
+        res = minimize(fun, np.array([4.0, -2.5]), method="BFGS", precision="float64", options={"maxiter": 12})
+        out_q.put((rank, np.asarray(res.x).copy(), float(res.fun), int(res.nfev), int(res.njev), losses))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("consistent", [True, False])
+def test_replicated_scipy_minimize_sees_identical_scalars(consistent):
+    """every rank runs the SAME SciPy loop (src/solver/scipy_autograd/scipy_minimize.py:100-117) on a loss that each
+    rank sums in its own order.  With the rank-0 scalars of round 6 both ranks must see bit-identical losses at every call, hence
+    take the same decisions: identical nfev / njev / x / fun.  The negative control (the exchange switched off) shows the stand-in's
+    jitter is visible to the optimiser at all -- there the recorded losses differ between the ranks."""
+    ctx = mp.get_context("spawn")
+    for attempt in range(3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_minimize_worker, args=(r, 2, port, consistent, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = []
+        try:
+            got = [q.get(timeout=240) for _ in range(2)]
+        except Exception:
+            pass
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+        if len(got) == 2 and all(p.exitcode == 0 for p in procs):
+            break
+        assert attempt < 2, [p.exitcode for p in procs]
+    got.sort(key=lambda g: g[0])
+    (_, x0, f0, nfev0, njev0, l0), (_, x1, f1, nfev1, njev1, l1) = got
+    if consistent:
+        assert nfev0 == nfev1 and njev0 == njev1 and nfev0 >= 3
+        assert l0 == l1  # every loss the optimiser saw, bit for bit
+        assert f0 == f1 and np.array_equal(x0, x1)
+    else:
+        n = min(len(l0), len(l1))
+        assert any(a != b for a, b in zip(l0[:n], l1[:n]))
 
 
 def test_time_slice_bounds_cover_everything():

@@ -150,3 +150,29 @@ def test_compact_copy_follows_the_work_list():
     res, grad = h.evaluate(desc, flow)
     gate("the big batch again", h, res, grad, ref)
     h.close()
+
+
+def test_short_runs_on_big_segments_take_the_plain_events():
+    """a dense objective that is neither `owned` (two reference times) nor long-run (4 events per pixel) runs the
+    kGradStrided K3, whose slot layout reads the 8-byte events; K1 of the same evaluation must then warp with the same fp32 time
+    (K3 follows K1's cells and windows without tests).  4.2M events on a 1024 x 1024 sensor with one hot tile (> 2040 events: the
+    standard cut is not group-aligned, so the work list is cut into big segments) -- such a handle gets no compact copy."""
+    size, n = (1024, 1024), 4_200_000
+    rng = np.random.default_rng(80)
+    ev = E.utils.generate_events(n, size[0], size[1], 0.0, 0.05, seed=80)
+    hot = rng.choice(n, 6000, replace=False)  # one hot source tile
+    ev[hot, 0] = rng.integers(512, 528, hot.size)
+    ev[hot, 1] = rng.integers(256, 272, hot.size)
+    flow = f32(E.utils.generate_smooth_flow(size, 9, seed=1081))
+    h = E.CMaxHandle(size).set_events(ev)
+    assert h.work_list_info()["segment_events"] == 4088, h.work_list_info()
+    for cost in ("multi_focal_normalized_image_variance", "image_variance"):  # three reference times (not owned) | one (owned)
+        desc = E.make_descriptor(cost, "dense-flow")
+        ref = orc.objective(ev, flow, "dense-flow", size, cost=cost, sigma=0)
+        for rep in range(2):
+            res, grad = h.evaluate(desc, flow)
+            e_loss = abs(res[0].item() - ref["loss"]) / abs(ref["loss"])
+            e_grad = rel_max(grad.double().cpu().numpy(), ref["grad"])
+            print(f"[compact] short runs on big segments, {cost} #{rep}: rel err loss {e_loss:.2e} grad {e_grad:.2e}")
+            assert e_loss <= TOL and e_grad <= TOL, (cost, e_loss, e_grad)
+    h.close()

@@ -255,7 +255,7 @@ def test_eight_ranks_sharing_one_gpu():
         assert abs(c["loss"] - c["loss_single"]) <= 2e-6 * abs(c["loss_single"])
         assert c["grad_rel_diff"] <= 2e-5  # fp32 atomics / another summation order; both are within 1e-4 of the oracle
         assert c["spread_over_ranks"] == 0.0  # an all-reduce leaves every rank with the same bits
-        assert c["loss_spread_over_ranks"] <= 1e-12 * abs(c["loss_single"])  # evaluated redundantly per rank: fp64 summation order
+        assert c["loss_spread_over_ranks"] == 0.0  # evaluated redundantly per rank in its own summation order, then made rank 0's (round 6)
 
 
 def test_patch_objective_two_ranks_with_unequal_and_empty_slices():
@@ -288,7 +288,7 @@ def test_patch_objective_two_ranks_with_unequal_and_empty_slices():
         # (the fall-back has no exact product: TorchWrapper's difference quotient of the sliced gradient picks up the objective's kinks at
         # every cell border and need not resemble the exact product -- what is asserted is that every rank computes the SAME numbers)
         assert np.isfinite(c["hvp_cosine"])
-        assert c["spread_over_ranks"] <= 1e-9 * max(1.0, abs(c["loss_single"]))
+        assert c["spread_over_ranks"] == 0.0  # loss (rank 0's scalars), gradient (all-reduced) and their difference quotient: the same bits
 
 
 @pytest.mark.parametrize("cost,sigma", [("image_variance", 0.0), ("gradient_magnitude", 1.0)])

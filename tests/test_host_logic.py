@@ -256,3 +256,22 @@ def test_pyramid_ops_and_feedback_keys():
     np.testing.assert_allclose(fb[2], P.pyramid_reduce(motions[3]))
     np.testing.assert_allclose(fb[1], P.pyramid_reduce(motions[2]))  # the optimised scale-2 motion, not the reduced feedback
     np.testing.assert_allclose(fb[0], P.pyramid_reduce(motions[1]))
+
+
+def test_grid_search_skips_nan_candidates(monkeypatch):
+    """initialize_guess_from_whole_image keeps `best_guess` unless `loss < best_loss` (patch_contrast_base.py:164-187): a NaN candidate
+    never wins, the FIRST minimum does, and a grid of NaNs leaves the reference's initial zeros(2)."""
+    from event_based_optical_flow_amd.solver import translation_search as ts
+
+    field = [-1.0, 0.0, 1.0]
+    losses = np.array([3.0, np.nan, 2.0, 2.0, np.nan, 5.0, np.nan, np.nan, 2.5])
+    monkeypatch.setattr(ts, "candidate_losses", lambda handle, cand, t_scale, **kw: losses.copy())
+    best, table = ts.grid_search_translation(None, 1.0, field)
+    assert np.array_equal(best, [-1.0, 1.0]) and table.shape == (3, 3) and np.isnan(table[0, 1])  # index 2: the first of the two 2.0
+    monkeypatch.setattr(ts, "candidate_losses", lambda handle, cand, t_scale, **kw: np.full(9, np.nan))
+    best, _ = ts.grid_search_translation(None, 1.0, field)
+    assert np.array_equal(best, np.zeros(2))
+    # a positive grid with one NaN: mapping NaN to 0.0 would have picked the NaN candidate
+    monkeypatch.setattr(ts, "candidate_losses", lambda handle, cand, t_scale, **kw: np.where(np.arange(9) == 4, np.nan, 1.0 + np.arange(9)))
+    best, _ = ts.grid_search_translation(None, 1.0, field)
+    assert np.array_equal(best, [-1.0, -1.0])
