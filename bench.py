@@ -141,6 +141,66 @@ def traffic_source(workload: str):
             "replayed, not measured in this run)" % os.path.relpath(paths[0], ROOT))
 
 
+PMC_CLASS = {"k_vote": "vote", "k_stats": "stats", "k_gimage": "gimage", "k_grad": "grad", "k_finish": "finish", "k_finish_deferred": "finish",
+             "k_finish_raw": "finish", "k_finish_lines": "finish", "k_stats_gimage_gm": "stats", "k_blur_stats_gimage_gm": "stats",
+             "k_blur_stats_var": "stats", "k_gimage_blur_adj_var": "gimage", "k_blur_stats_adj_var": "stats"}
+
+
+def pmc_traffic_this_run(workload: str, timeout_s: float = 150.0):
+    """HBM-side bytes per launch of the workload's kernels measured ON THIS BOX, NOW: this script re-executed twice
+    under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, no tracing option beside --pmc, as
+    MI355X_MICROARCH.md's HBM section prescribes -- with a short run of the same workload; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB
+    (gfx950 tallies the 128-byte requests of a wide coalesced read at 64: FETCH_SIZE doubled; WRITE_SIZE as reported).  Returns
+    ({class: bytes per launch}, description) or (None, reason).  Never raises: the replayed summary under profiles/ is the fall-back."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="cmax_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "-o", "c", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu-baseline", "--no-also", "--no-pmc", "--windows", "2", "--steps", "20", "--warmup", "3", "--ramp", "0",
+                   "--workload", workload, "--verbose-out", os.path.join(tmp, "line.json")]
+            try:
+                p = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out after %.0f s" % (ctr, timeout_s)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s: rc %d, %d counter file(s): %s" % (ctr, p.returncode, len(files), (p.stderr or "")[-160:].replace("\n", " "))
+            per = collections.defaultdict(list)
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == ctr:
+                    per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            for kname, vals in per.items():
+                m = re.search(r"cmax::(?:[tbm]\d+::)?(k_\w+)", kname)
+                if m and len(vals) >= 10:
+                    raw.setdefault(m.group(1), {})[ctr] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = {}
+    for kname, v in raw.items():
+        cls = PMC_CLASS.get(kname)
+        if cls and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            traffic[cls] = traffic.get(cls, 0) + int(round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))
+    if not traffic:
+        return None, "no counter rows for the workload's kernels"
+    return traffic, ("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of `bench.py --workload %s --steps 20 "
+                     "--windows 2` on this box, no tracing); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, mean over launches" % workload)
+
+
 def make_inputs(cfg, rank, world, seed=46, structured=False):
     """This rank's time slice [rank, rank + 1) * period / world of the batch (host fp64 [n, 4]) and the motion."""
     import event_based_optical_flow_amd as E
@@ -370,20 +430,40 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
         for _ in range(200):
             step()
         torch.cuda.synchronize()
-    times = []
+    # Every window of EXACTLY `steps` evaluations sits between barrier + synchronize on both sides and is timed twice: with HIP events
+    # recorded on the launch stream (torch's current stream IS the stream the library launches on, functional._stream) --
+    # `value` -- and with the host clock around the closing synchronize (round 1-5's figure, kept as host_clock_*: it contains the
+    # synchronize's return latency, a few us per 340-us window that moved with the box).
+    times, host_times = [], []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    settle = []  # headline row only: untimed windows until the clocks have settled (two consecutive windows within 1 % of the best), <= 6 s
+    t_settle = time.perf_counter()
+    while keep_inputs and args.ramp > 0 and world == 1 and time.perf_counter() - t_settle < 6.0:
+        ev0.record()
+        for _ in range(max(steps, 100)):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        settle.append(ev0.elapsed_time(ev1))
+        if len(settle) >= 4 and max(settle[-2:]) <= 1.01 * min(settle):
+            break
     for _ in range(windows):
         sync_all()
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(steps):
             res, grad = step()
+        ev1.record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        times.append(time.perf_counter() - t0)
-    times = torch.tensor(times, dtype=torch.float64, device=dev)
+        host_times.append(time.perf_counter() - t0)
+        times.append(ev0.elapsed_time(ev1) * 1e-3)
+    both = torch.tensor([times, host_times], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)  # a window lasts as long as its slowest rank
-    times = np.sort(times.cpu().numpy())
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)  # a window lasts as long as its slowest rank
+    both = both.cpu().numpy()
+    times, host_times = np.sort(both[0]), np.sort(both[1])
     elapsed = float(np.median(times))
     loss = float(finalize()[0][0]) if finalize else float(res[0].item() if hasattr(res[0], "item") else res[0])
     n_total = n_local * world
@@ -392,7 +472,8 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
            "cost": cfg["cost"], "blur_sigma": cfg["sigma"], "time_bins": T,
            "ms_per_step": elapsed / evals * 1e3, "value": n_total * evals / elapsed,
            "window_ms_per_step": {"min": float(times[0]) / evals * 1e3, "median": elapsed / evals * 1e3, "max": float(times[-1]) / evals * 1e3,
-                                  "windows": windows, "steps_per_window": evals},
+                                  "windows": windows, "steps_per_window": evals, "clock": "HIP events on the launch stream",
+                                  "host_clock_median": float(np.median(host_times)) / evals * 1e3},
            "loss": loss, "prepare_ms_once_per_batch": prepare_ms, "collectives": sliced.collectives, "deterministic": bool(args.deterministic),
            "result_form": {"raw": "raw sums on the device, folded by the consumer on the host (cmax_objective_raw + cmax_finalize_raw_host)",
                            "device": "loss + gradient on the device (cmax_objective)",
@@ -448,6 +529,13 @@ def run_workload(name, args, rank, world, dev, steps, warmup, windows, profile=T
         out["dominant"] = max((k for k in hot if k in kernels), key=lambda k: kernels[k]["launch_us"])
         out["profile_method"] = ("HIP events on the launch stream; each bracket of a hot class holds %d back-to-back launches of the "
                                  "kernel (instrumented passes after the timed region, same inputs; median of 5 passes)" % REPEAT)
+    # counter bytes of one evaluation (profiles/r*_pmc_<workload>.json: FETCH_SIZE x 2 + WRITE_SIZE per launch, summed over the kernel
+    # classes) / step time = the PHYSICAL rate through the memory-side counters, beside the algorithmic fraction: the packed event is
+    # 8 or 4.5 bytes where SURVEY 8(d) charges 12, so the two differ by up to 2.3x on the large rows
+    phys = [measured_traffic(name, k) for k in ("vote", "stats", "gimage", "grad", "finish")]
+    if any(phys):
+        out["physical_bytes_per_evaluation"] = int(sum(v for v in phys if v))
+        out["physical_GBps"] = out["physical_bytes_per_evaluation"] / (out["ms_per_step"] * 1e-3) / 1e9
     if keep_inputs:
         out["_inputs"] = (cfg, ev, motion)
         if world == 1:
@@ -604,13 +692,21 @@ def compact_line(out, verbose_path):
                                      "bytes": dom["algorithmic_bytes_per_launch"], "traffic": dom["traffic"]},
                         "kernels_us": {k: _r(v.get("launch_us", v.get("single_launch_bracket_us"))) for k, v in r["kernels"].items()},
                         "launch_floor_us": _r(r.get("launch_floor_us")), "frac_raw_form": _r(r.get("frac_raw_form")),
-                        "frac_host_result": _r(r.get("frac_host_result"))}
+                        "frac_host_result": _r(r.get("frac_host_result")), "frac_batch8": _r(r.get("frac_batch8")),
+                        "frac_batch32": _r(r.get("frac_batch32")), "frac_host_clock": _r(r.get("frac_host_clock")),
+                        "physical_GBps": _r(r.get("physical_GBps")), "traffic_source": (r.get("traffic_source") or "")[:60] or None}
     line["timing_us"] = {k: _r(out["timing"][k] * 1e3) for k in ("min", "median", "max")}
+    if "host_clock_median" in out["timing"]:  # (records of rounds 1-5 were timed with the host clock alone)
+        line["timing_us"]["clock"] = "hip_events"
+        line["timing_us"]["host_clock_median"] = _r(out["timing"]["host_clock_median"] * 1e3)
     line["prepare_ms_once_per_batch"] = _r(out["prepare_ms_once_per_batch"])
     line["loss"] = _r(out["loss"], 8)
     if out.get("also"):
         line["configs"] = {k: {"us": _r(a["ms_per_step"] * 1e3), "frac": _r(a["evaluation_frac"]), "dom_us": _r(a["dominant_kernel_us"]),
                                "prep_ms": _r(a["prepare_ms_once_per_batch"], 3)} for k, a in out["also"].items()}
+        for k, a in out["also"].items():  # physical rate through the memory-side counters, where a counter summary of the row exists
+            if a.get("physical_GBps"):
+                line["configs"][k]["phys_GBps"] = _r(a["physical_GBps"], 3)
         if out["n_gpus"] > 1:
             for k, a in out["also"].items():
                 line["configs"][k]["value"] = _r(a["value"], 5)
@@ -705,6 +801,8 @@ def main():
                          "finished on the device; raw = cmax_objective_raw where the objective has that form (2-DoF), the consumer folds "
                          "the partial sums; host = cmax_objective_host (every step waits for its numbers)")
     ap.add_argument("--deterministic", action="store_true", help="cmax_set_deterministic(1): integer accumulation, bit-repeatable results (slower)")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not re-execute the headline workload under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                    "for roofline.traffic (two short passes, ~40 s); the committed counter summary under profiles/ is replayed instead")
     ap.add_argument("--verbose", action="store_true", help="print the full record (per-kernel dictionaries, every row's windows: ~30 KB) instead "
                     "of the compact line; the full record is written to --verbose-out either way")
     ap.add_argument("--verbose-out", default=None, help="file for the full record (default gpurun_out/bench_verbose_<workload>_n<N>.json)")
@@ -736,9 +834,6 @@ def main():
     launch_affinity = set(os.sched_getaffinity(0))  # what the launcher allowed (the CPU baselines run on all of it)
     host_affinity = None if args.no_pin else pin_to_gpu_numa_node(dev.index)
 
-    main_res = run_workload(args.workload, args, rank, world, dev, args.steps, args.warmup, args.windows, keep_inputs=True)
-    cfg, ev, motion = main_res.pop("_inputs")
-
     also = {}
     if not args.no_also:
         # the other configurations, fewer steps (their evaluations are 2-10x longer); same timing protocol
@@ -763,7 +858,28 @@ def main():
                            "dominant_kernel_us": r["kernels"][dom]["launch_us"] if dom else None,
                            "dominant_kernel_frac": r["kernels"][dom]["frac"] if dom else None,
                            "kernels_us": {k: v.get("launch_us", v.get("single_launch_bracket_us")) for k, v in r.get("kernels", {}).items()},
+                           "physical_GBps": r.get("physical_GBps"), "host_clock_ms_per_step": r["window_ms_per_step"]["host_clock_median"],
                            "collectives": r["collectives"], "prepare_ms_once_per_batch": r["prepare_ms_once_per_batch"]}
+
+    # The headline row runs LAST, behind the other rows' ~40 s of GPU work (round 6): a process that starts on an idle box measures its
+    # first seconds in a lower power state -- the default command as the FIRST GPU process on a fresh box gave K1 / K3 7.3 / 7.1 us and
+    # 18.2 us per evaluation, the same command behind a test run 6.5 / 6.6 and 15.2 (gpurun_out/r06_bench_a / _b) -- and the 1.5 s ramp
+    # does not cover it.  Its own W warm-up steps and the ramp still precede its K timed steps.
+    main_res = run_workload(args.workload, args, rank, world, dev, args.steps, args.warmup, args.windows, keep_inputs=True)
+    cfg, ev, motion = main_res.pop("_inputs")
+
+    # roofline.traffic measured in THIS run (N = 1; the sub-runs pass --no-pmc): else the replayed summary of an earlier run
+    pmc_traffic, pmc_note = None, None
+    if world == 1 and not args.no_pmc and not args.deterministic:
+        torch.cuda.synchronize()
+        pmc_traffic, pmc_note = pmc_traffic_this_run(args.workload)
+        if pmc_traffic:
+            for k, v in main_res.get("kernels", {}).items():
+                if k in pmc_traffic:
+                    v["traffic"] = pmc_traffic[k]
+            ptotal = sum(pmc_traffic.get(k, 0) for k in ("vote", "stats", "gimage", "grad", "finish"))
+            main_res["physical_bytes_per_evaluation"] = ptotal
+            main_res["physical_GBps"] = ptotal / (main_res["ms_per_step"] * 1e-3) / 1e9
 
     comm_probe = None
     if world > 1:
@@ -805,11 +921,19 @@ def main():
                          # the same evaluation in its other two forms (also.cfg2_raw / also.cfg2_host_result), when those rows ran
                          "frac_raw_form": also.get("cfg2_raw", {}).get("evaluation_frac") if args.workload == "cfg2" else None,
                          "frac_host_result": also.get("cfg2_host_result", {}).get("evaluation_frac") if args.workload == "cfg2" else None,
+                         # ... and per evaluation of a K-candidate call (cmax_objective_batch): the only form of the 1M-event evaluation that
+                         # clears 0.40 -- a single evaluation is a chain of launch latencies (launch_floor_us)
+                         "frac_batch8": also.get("cfg2_batch8", {}).get("evaluation_frac") if args.workload == "cfg2" else None,
+                         "frac_batch32": also.get("cfg2_batch32", {}).get("evaluation_frac") if args.workload == "cfg2" else None,
+                         "frac_host_clock": main_res["evaluation_frac"] * main_res["ms_per_step"] / main_res["window_ms_per_step"]["host_clock_median"],
+                         "physical_GBps": main_res.get("physical_GBps"),
                          # two dependent EMPTY launches with this evaluation's grids, measured in this run (cmax_debug_launch_floor)
                          "launch_floor_us": main_res.get("launch_floor_us"),
                          "algorithmic_bytes_per_evaluation": main_res["evaluation_bytes_per_gpu"],
-                         "traffic": sum(v for v in (measured_traffic(args.workload, k) for k in ("vote", "stats", "gimage", "grad", "finish")) if v) or None,
-                         "traffic_source": traffic_source(args.workload),
+                         "traffic": (sum(pmc_traffic.get(k, 0) for k in ("vote", "stats", "gimage", "grad", "finish")) if pmc_traffic else
+                                     sum(v for v in (measured_traffic(args.workload, k) for k in ("vote", "stats", "gimage", "grad", "finish")) if v) or None),
+                         "traffic_source": pmc_note if pmc_traffic else traffic_source(args.workload),
+                         "traffic_this_run_error": None if (pmc_traffic or args.no_pmc or world > 1) else pmc_note,
                          "dominant": {"kernel": kd["kernel"], "achieved": kd["GBps"], "frac": kd["frac"], "launch_us": kd["launch_us"],
                                       "algorithmic_bytes_per_launch": kd["algorithmic_bytes_per_launch"], "traffic": kd["traffic"]},
                          "kernels": main_res["kernels"], "method": main_res["profile_method"]},

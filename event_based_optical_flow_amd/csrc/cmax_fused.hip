@@ -483,6 +483,13 @@ __global__ void __launch_bounds__(1024) k_scan_small(int *__restrict__ counts, i
 // ---------------------------------------------------------------------------------------------
 // per-event warp shared by K1 and K3
 // ---------------------------------------------------------------------------------------------
+// v_cvt_flr_i32_f32: (int)floor(x) in one instruction, saturating
+__device__ __forceinline__ int cvt_flr(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 struct Warped {
     int row, col;  // top-left corner in the padded image
     float a, b;    // row / column fractions
@@ -541,12 +548,17 @@ __device__ __forceinline__ Warped warp_one(const EvView &ev, const EvDec &e, con
     }
     // floor(x' + 1e-6) = ix + floor(dx + 1e-6) exactly because ix is an integer
     // (bilinear_vote_tensor, src/event_image_converter.py:340-345)
+    // Round 6 (VALU diet): v_floor_f32 + v_cvt_i32_f32 per coordinate; the v_med3_f32 between them (a clamp to +-8192) is gone:
+    // a displacement beyond +-8192 px (a diverged or non-finite motion) now lands on whatever cell the saturated conversion names --
+    // (v_cvt_i32_f32 saturates) -- its packed (row, col) word may wrap, but every consumer derives box, window and indices from the SAME word, so such an event
+    // is either outside every window of the fast path's 8192 words (-> the clipped path, whose every corner is tested against window
+    // and image) or votes in bounds; it was never defined where.
     const float fx = floorf(dx + 1e-6f), fy = floorf(dy + 1e-6f);
-    w.a = dx - fx;
+    const int fxi = (int)fx, fyi = (int)fy;  // (v_cvt_i32_f32 saturates; through inline asm v_cvt_flr_i32_f32 + v_cvt_f32_i32 are two instructions as well, but
+    w.a = dx - fx;                           // the asm operands cost the 512 x 8 K3 eleven VGPRs, i.e. a wave per SIMD)
     w.b = dy - fy;
-    const float cx = fminf(fmaxf(fx, -8192.f), 8192.f), cy = fminf(fmaxf(fy, -8192.f), 8192.f);
-    w.row = ix + (int)cx + (int)(eb.row + (unsigned)wp.ph);
-    w.col = iy + (int)cy + (int)(eb.col + (unsigned)wp.pw);
+    w.row = ix + fxi + (int)(eb.row + (unsigned)wp.ph);
+    w.col = iy + fyi + (int)(eb.col + (unsigned)wp.pw);
     return w;
 }
 
@@ -721,6 +733,19 @@ __device__ __forceinline__ void zero_fill_sc1(float *base, int64_t n, int64_t ti
 __device__ __forceinline__ int cvt_rpi(float x) {
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// v_mad_u32_u16 with the HIGH half of `packed` as first factor: (packed >> 16) * factor + addend in one instruction (`factor` wave-uniform,
+// below 2^16), and v_add_u32 with the LOW half of `packed` through SDWA: the LDS word of a packed (row, col) in two instructions where
+// shift, mask, multiply-add and add were four
+__device__ __forceinline__ unsigned mad_hi16_u(unsigned packed, unsigned factor, unsigned addend) {
+    unsigned r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(factor), "v"(addend));
+    return r;
+}
+__device__ __forceinline__ unsigned add_lo16_u(unsigned a, unsigned packed) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(packed));
     return r;
 }
 // 24-bit multiplies with a UNIFORM second factor, spelled out: the compiler takes v_mul_lo_u32 / v_mul_hi_u32 whenever it cannot

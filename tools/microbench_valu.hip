@@ -73,6 +73,18 @@ __global__ void __launch_bounds__(512, 8) k_valu(float *out, int iters, float se
             if (MODE == 46) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x[i]));
             if (MODE == 47) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(x[i]));
             if (MODE == 48) asm volatile("v_ldexp_f32 %0, %0, 3" : "+v"(x[i]));
+            if (MODE == 49) asm volatile("v_mad_u32_u16 %0, %0, %1, %2 op_sel:[1,0,0,0]" : "+v"(x[i]) : "s"(c0), "v"(c1));
+            if (MODE == 50) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(x[i]) : "v"(c1));
+            if (MODE == 51) asm volatile("v_cvt_flr_i32_f32 %0, %0" : "+v"(x[i]));
+            // floor by a round-down add of 1.5 * 2^23 between two mode switches, two adds per switch pair (the warp's x and y)
+            if (MODE == 52 && (i & 1) == 0) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\tv_add_f32 %0, 0x4b400000, %0\n\tv_add_f32 %1, 0x4b400000, %1\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "+v"(x[i]), "+v"(x[i + 1]));
+            if (MODE == 53) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(x[i]) : "v"(c0));
+            if (MODE == 54) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(x[i]) : "s"(c0), "v"(c1));
+            if (MODE == 55) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[i]) : "s"(c0));
+            if (MODE == 56) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
+            if (MODE == 57) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x[i]));
+            if (MODE == 58) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(x[i]));
+            if (MODE == 59) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
         }
     }
     float s = 0.f;
@@ -154,5 +166,16 @@ int main(int argc, char **argv) {
     run("v_bfi_b32", k_valu<44>);
     run("v_perm_b32", k_valu<45>);
     run("alternating v_fma_f32 / v_bfe_u32", k_valu<33>);
+    run("v_mad_u32_u16 op_sel hi, SGPR factor", k_valu<49>);
+    run("v_add_u32_sdwa src1 WORD_0", k_valu<50>);
+    run("v_cvt_flr_i32_f32", k_valu<51>);
+    run("round-down v_add_f32 x2 between 2 s_setreg (per add)", k_valu<52>);
+    run("v_pk_min_u16", k_valu<53>);
+    run("v_mad_i32_i24 SGPR factor", k_valu<54>);
+    run("v_sub_u32 SGPR", k_valu<55>);
+    run("v_and_or_b32", k_valu<56>);
+    run("v_cvt_f32_ubyte0", k_valu<57>);
+    run("v_lshrrev_b32 8", k_valu<58>);
+    run("v_med3_i32", k_valu<59>);
     return 0;
 }
