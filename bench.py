@@ -559,6 +559,24 @@ def comm_model_us(nbytes, world):
     return alpha + (wire if world <= 2 else 2.0 * wire / world)
 
 
+# The partition DESIGN section 5 names beside BASELINE's time slices: rank r owns a BAND OF SOURCE TILE ROWS (every event whose source pixel
+# lies in it, whatever its time).  Its events vote into its own rows plus a halo of max |flow dt| rows on either side, so C1 shrinks from an
+# all-reduce of the image to two neighbour exchanges of halo rows (partial sums to the owner, finished rows back), the image statistics become
+# an all-reduce of two doubles, and a dense flow gradient needs no C2 at all (every source pixel has one owner; the solver's patch gradient
+# stays a 4 KB all-reduce).  Assumed like COMM_MODEL: alpha_p2p = 8 us per grouped send / receive pair, beta = 100 GB/s per link.
+BAND_MODEL = {"alpha_p2p_us": 8.0, "halo_rows": 20}
+
+
+def band_model_us(compute_us, width, world, halo_rows=None, patch_gradient=True):
+    """One evaluation under the row-band partition: compute + 2 halo exchanges + the statistics' all-reduce (+ the patch gradient's)."""
+    if world <= 1:
+        return compute_us
+    halo = BAND_MODEL["halo_rows"] if halo_rows is None else halo_rows
+    wire = halo * width * 4 / (COMM_MODEL["beta_GBps"] * 1e3)  # us per direction and exchange (both neighbours in parallel on their own links)
+    chain = 2.0 * (BAND_MODEL["alpha_p2p_us"] + wire) + comm_model_us(16, world)
+    return compute_us + chain + (comm_model_us(4096, world) if patch_gradient else 0.0)
+
+
 def comm_probe_run(dev, world, rank, args, reps=50):
     """N > 1: the collectives of an evaluation measured ON THEIR OWN, beside what DESIGN section 5's model predicts for them, so that one
     SCALE record confirms or refutes the model.  Sizes: the 16-byte 2-DoF gradient, the 4 KB gradient of the solver's

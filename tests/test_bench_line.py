@@ -50,3 +50,14 @@ def test_comm_model_matches_the_design_table():
     assert abs(bench.comm_model_us(c1, 8) - (25 + 9.2)) < 0.2
     assert abs(bench.comm_model_us(2 * c1, 8) - (25 + 18.4)) < 0.2
     assert abs(bench.comm_model_us(16, 8) - 25.0) < 0.01
+
+
+def test_band_model_matches_the_design_table():
+    """DESIGN.md section 5, row-band partition of cfg5 (1280 wide, 20 halo rows = 102 KB per exchange and direction = 1.0 us on the wire):
+    two exchanges at 8 + 1 us, the statistics' all-reduce at alpha(N), the patch gradient's 4 KB at alpha(N) + its wire time."""
+    import bench
+
+    assert abs(bench.band_model_us(27.5, 1280, 8) - (27.5 + 2 * (8 + 1.024) + 25.0 + 25.0 + 0.01)) < 0.1
+    assert abs(bench.band_model_us(48.0, 1280, 2) - (48.0 + 2 * (8 + 1.024) + 12.0 + 12.04)) < 0.1
+    assert abs(bench.band_model_us(27.5, 1280, 8, patch_gradient=False) - (27.5 + 18.05 + 25.0)) < 0.1
+    assert bench.band_model_us(85.0, 1280, 1) == 85.0
