@@ -152,7 +152,8 @@ struct ImgArgs {
 
 // Phase timeline of the event kernels (builds with -DCMAX_TIMELINE only, tools/timeline.py): thread 0 of the first 4096 workgroups of
 // reference time 0 stamps the 100 MHz wall clock at the phase boundaries of K1 (kernel 0) and K3 (kernel 1) into
-// g_timeline[kernel][workgroup][8]; a stamp that is to follow the arrival of loaded data is handed a value computed from it.
+// g_timeline[kernel][workgroup][8] (round 6: kernel 2 = the fused image kernel between them); a stamp that is to follow the arrival of
+// loaded data is handed a value computed from it.
 #ifdef CMAX_TIMELINE
 namespace cmax {
 __device__ unsigned long long *g_timeline = nullptr;
@@ -1083,10 +1084,14 @@ k_stats_gimage_gm(const float *__restrict__ in0, int64_t in_stride, int H, int W
     const int tiles_w = (W + kGmTileW - 1) / kGmTileW;
     const int tr = blockIdx.x / tiles_w, tc = blockIdx.x - tr * tiles_w;
     const int r0 = tr * kGmTileH - 2, c0 = tc * kGmTileW - 2;
+    CMAX_STAMP(2, 0);
     stage_tile<kGmTileH + 4, kGmTileW + 4>(tile, img, r0, c0, H, W);
+    CMAX_STAMP_AFTER(2, 1, tile[0][0]);
     __syncthreads();
+    CMAX_STAMP(2, 2);
     if (blockIdx.y == 0) zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
+    CMAX_STAMP(2, 3);
     const int i0 = omit ? 1 : 0;
     const float gscale = (float)((2.0 / region_pixels(H, W, omit)) / 8.0) * ia.chain[blockIdx.y];
     const int la = threadIdx.x / kGmTileW, lb = threadIdx.x - la * kGmTileW;  // pixel of this thread inside the tile
@@ -1140,8 +1145,11 @@ k_stats_gimage_gm(const float *__restrict__ in0, int64_t in_stride, int H, int W
         G[p] = gscale * s;
         if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) v[0] = (double)(gx[1][1] * gx[1][1] + gy[1][1] * gy[1][1]);
     }
+    CMAX_STAMP(2, 5);
     block_sum<2>(v, smem);
+    CMAX_STAMP(2, 6);
     if (threadIdx.x == 0) atomic_add(&stat_slot[kSubStride * (blockIdx.x % nsub)], v[0]);
+    CMAX_STAMP(2, 7);
 }
 
 // Blurred gradient-magnitude cost (the shipped YAML cost), whole image side of one reference time in ONE kernel:
@@ -1270,8 +1278,11 @@ k_blur_stats_adj_var(const float *__restrict__ in0, int64_t in_stride, int H, in
     const int R0 = tr * TH, C0 = tc * TW;  // top-left output pixel
     const int i0 = omit ? 1 : 0;
     auto in_img = [&](int r, int c) { return (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W; };
+    CMAX_STAMP(2, 0);
     stage_tile<TH + 4, TW + 4>(t_i, img, R0 - 2, C0 - 2, H, W);
+    CMAX_STAMP_AFTER(2, 1, t_i[0][0]);
     __syncthreads();
+    CMAX_STAMP(2, 2);
     zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
     for (int q = threadIdx.x; q < (TH + 2) * (TW + 2); q += 256) {
@@ -1285,7 +1296,9 @@ k_blur_stats_adj_var(const float *__restrict__ in0, int64_t in_stride, int H, in
         }
         t_b[a][b] = v;
     }
+    CMAX_STAMP(2, 3);
     __syncthreads();
+    CMAX_STAMP(2, 4);
     const float gscale = (float)(2.0 / (region_pixels(H, W, omit) - 1.0)) * ia.chain[blockIdx.y];
     const int la = threadIdx.x / TW, lb = threadIdx.x - la * TW;
     const int i = R0 + la, j = C0 + lb;
@@ -1305,12 +1318,15 @@ k_blur_stats_adj_var(const float *__restrict__ in0, int64_t in_stride, int H, in
             v[1] = (double)b * (double)b;
         }
     }
+    CMAX_STAMP(2, 5);
     block_sum<2>(v, smem);
+    CMAX_STAMP(2, 6);
     if (threadIdx.x == 0) {
         double *a = stat_slot + kSubStride * (blockIdx.x % nsub);
         atomic_add(&a[0], v[0]);
         atomic_add(&a[1], v[1]);
     }
+    CMAX_STAMP(2, 7);
 }
 
 // b(p) of B = blur3^T 1_Omega along one axis of length n >= 4 (Omega = [i0, n - i0)): b(0) = b(n - 1), b(1) = b(n - 2), 1 elsewhere

@@ -92,7 +92,9 @@ def test_objective_dist_world1_rccl(world1_nccl, model, cost, sigma, Tn):
         res_d, grad_d = h.evaluate_dist(desc, motion)
     torch.cuda.synchronize()
     assert abs(res_d[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())  # the vote flush is fp32 atomics: order varies
-    assert rel_max(grad_d.cpu().numpy(), grad.cpu().numpy()) <= 2e-6  # fp32 atomics: order differs run to run
+    # fp32 atomics: order differs run to run; the 2-DoF variance also takes the tangent-image path here (planes in 14.18 fixed point) against the
+    # per-event gather of `evaluate`: two roundings of the same sum, each within 1e-4 of the oracle (below)
+    assert rel_max(grad_d.cpu().numpy(), grad.cpu().numpy()) <= 5e-6
     ref = orc.objective(ev, motion, model, size, cost=cost, sigma=int(sigma))
     assert abs(res_d[0].item() - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_max(grad_d.cpu().numpy(), ref["grad"]) <= TOL

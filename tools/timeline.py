@@ -16,6 +16,8 @@ from event_based_optical_flow_amd import _lib  # noqa: E402
 
 K1 = ["entry", "events+flows arrived, warped", "box reduced", "barrier 1 + window + LDS zero issued", "barrier 2 (+ offsets)", "votes done", "barrier 3", "flush issued"]
 K3 = ["entry", "window staged + events warped", "barrier", "gather done", "barrier (accumulators)", "flush / scan done", "sums reduced", "-"]
+# round 6: the fused image kernels between K1 and K3 (k_blur_stats_adj_var, k_stats_gimage_gm / k_blur_stats_gimage_gm), kernel index 2
+KI = ["entry", "tile loads arrived", "barrier 1 (tile staged)", "clears issued + inner tile", "barrier 2", "outputs stored", "block sum (2 barriers)", "statistics' atomics issued"]
 
 
 def run(name):
@@ -34,17 +36,17 @@ def run(name):
     for _ in range(50):
         call()
     torch.cuda.synchronize()
-    buf = torch.zeros(2 * 4096 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(3 * 4096 * 8, dtype=torch.int64, device=dev)
     lib = _lib.load()
     _lib.check(lib.cmax_debug_timeline(ctypes.c_void_p(buf.data_ptr())))
     call()
     torch.cuda.synchronize()
     _lib.check(lib.cmax_debug_timeline(None))
-    t = buf.cpu().numpy().reshape(2, 4096, 8).astype(np.float64)
+    t = buf.cpu().numpy().reshape(3, 4096, 8).astype(np.float64)
     info = h.work_list_info()
     print(f"== {name}: {cfg['desc']} -- {info['segments']} segments of <= {info['segment_events']} events")
     t00 = None
-    for k, names in ((0, K1), (1, K3)):
+    for k, names in ((0, K1), (2, KI), (1, K3)):
         a = t[k]
         live = a[:, 0] > 0
         a = a[live]
@@ -54,7 +56,7 @@ def run(name):
         if t00 is None:
             t00 = start
         last = np.max(np.where(a > 0, a, 0), axis=1)
-        print(f" K{1 if k == 0 else 3}: {len(a)} workgroups stamped; first starts at {(start - t00) / 100:.2f} us, starts spread over {(a[:, 0].max() - start) / 100:.2f} us, "
+        print(f" {('K1', 'K3', 'image kernel')[k]}: {len(a)} workgroups stamped; first starts at {(start - t00) / 100:.2f} us, starts spread over {(a[:, 0].max() - start) / 100:.2f} us, "
               f"last stamp at {(last.max() - t00) / 100:.2f} us (span {(last.max() - start) / 100:.2f} us)")
         prev = 0
         for i in range(1, 8):
