@@ -1279,22 +1279,45 @@ k_blur_stats_adj_var(const float *__restrict__ in0, int64_t in_stride, int H, in
     const int i0 = omit ? 1 : 0;
     auto in_img = [&](int r, int c) { return (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W; };
     CMAX_STAMP(2, 0);
-    stage_tile<TH + 4, TW + 4>(t_i, img, R0 - 2, C0 - 2, H, W);
+    // Round 6: BRANCH-FREE STENCILS.  tools/timeline.py had the two stencil phases of this kernel at 1.0 + 1.5 us of its workgroups' 4.8
+    // (predicated taps: reflection, image and Omega tests per tap, each an LDS round trip behind a branch), and the tiles along the border
+    // -- the slowest workgroups ARE the kernel's span -- at the same cost as everybody else.  Now the border is resolved where the tiles
+    // are filled: the raw tile is staged WITH its reflect-101 halo (in-image reads only), the forward blur is a plain 3 x 3 stencil, the
+    // masked, centred image d = (Ib - mu) 1_Omega gets a tile of its own, and blur^T is a 3 x 3 stencil on d whose per-axis tap weights
+    // (k1, k0, k1; 0 beyond the image; 2 k1 for the reflected taps folded back onto rows / columns 1 and n - 2) are set up once per thread.
+    {
+        constexpr int kN = (TH + 4) * (TW + 4), kIt = (kN + 255) / 256;
+        float x[kIt];
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int q = min((int)threadIdx.x + 256 * u, kN - 1), a = q / (TW + 4), b = q - a * (TW + 4);
+            const int r = refl101(min(max(R0 - 2 + a, -2), H + 1), H), c = refl101(min(max(C0 - 2 + b, -2), W + 1), W);  // (H, W >= 4: the host's condition for this kernel)
+            x[u] = img[(int64_t)r * W + c];
+        }
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) pin(x[u]);  // all loads in flight before the first LDS store (see pin())
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int q = threadIdx.x + 256 * u, a = q / (TW + 4), b = q - a * (TW + 4);
+            if (q < kN) t_i[a][b] = x[u];
+        }
+    }
     CMAX_STAMP_AFTER(2, 1, t_i[0][0]);
     __syncthreads();
     CMAX_STAMP(2, 2);
     zero_fill_sc1((float *)zero_extra, 4 * n_extra4, gtid, gthreads);  // behind the loads (see k_stats)
     zero_fill_sc1(zero_img, (int64_t)H * W, gtid, gthreads);
-    for (int q = threadIdx.x; q < (TH + 2) * (TW + 2); q += 256) {
-        const int a = q / (TW + 2), b = q - a * (TW + 2), r = R0 - 1 + a, c = C0 - 1 + b;
-        float v = 0.f;
-        if (in_img(r, c)) {  // reflect-101 neighbours are at most one pixel away: inside the halo-2 tile
-            const int rm = refl101(r - 1, H) - (R0 - 2), rr = r - (R0 - 2), rp = refl101(r + 1, H) - (R0 - 2);
-            const int cm = refl101(c - 1, W) - (C0 - 2), cc = c - (C0 - 2), cp = refl101(c + 1, W) - (C0 - 2);
-            auto row = [&](int y) { return k1 * t_i[y][cm] + k0 * t_i[y][cc] + k1 * t_i[y][cp]; };
-            v = k1 * row(rm) + k0 * row(rr) + k1 * row(rp);
+    __shared__ float t_d[TH + 2][TW + 2 + 1];  // (Ib - mu) 1_Omega, halo 1
+    {
+        const float mu = s_mu;  // (published by the barrier above)
+        for (int q = threadIdx.x; q < (TH + 2) * (TW + 2); q += 256) {
+            const int a = q / (TW + 2), b = q - a * (TW + 2), r = R0 - 1 + a, c = C0 - 1 + b;  // t_b[a][b] = pixel (r, c) = t_i[a + 1][b + 1]
+            auto row = [&](int y) { return k1 * t_i[y][b] + k0 * t_i[y][b + 1] + k1 * t_i[y][b + 2]; };
+            const float vb = k1 * row(a) + k0 * row(a + 1) + k1 * row(a + 2);  // (the products and their order are k_blur3's)
+            const bool in_om = r >= i0 && r < H - i0 && c >= i0 && c < W - i0;
+            t_b[a][b] = in_img(r, c) ? vb : 0.f;
+            t_d[a][b] = in_om ? vb - mu : 0.f;
         }
-        t_b[a][b] = v;
     }
     CMAX_STAMP(2, 3);
     __syncthreads();
@@ -1307,12 +1330,12 @@ k_blur_stats_adj_var(const float *__restrict__ in0, int64_t in_stride, int H, in
         const int64_t p = (int64_t)i * W + j;
         const float b = t_b[la + 1][lb + 1];
         blurred[p] = b;
-        const float mu = s_mu;  // (published by the barriers above)
-        auto d = [&](int r, int c) -> float {  // (Ib - mu) 1_Omega
-            const bool in = (r >= i0) && (r < H - i0) && (c >= i0) && (c < W - i0);
-            return in ? t_b[r - (R0 - 1)][c - (C0 - 1)] - mu : 0.f;
-        };
-        G[p] = gscale * blur_adj_1d<float>(i, H, k0, k1, [&](int r) { return blur_adj_1d<float>(j, W, k0, k1, [&](int c) { return d(r, c); }); });
+        // blur^T along one axis of length n at index q: weight of d[q - 1] and of d[q + 1] (blur_adj_1d: a tap beyond the image does not exist;
+        // rows / columns 1 and n - 2 also receive the reflected tap of their outer neighbour)
+        const float rm = i >= 1 ? (i == 1 ? 2.f * k1 : k1) : 0.f, rp = i + 1 < H ? (i == H - 2 ? 2.f * k1 : k1) : 0.f;
+        const float cm = j >= 1 ? (j == 1 ? 2.f * k1 : k1) : 0.f, cp = j + 1 < W ? (j == W - 2 ? 2.f * k1 : k1) : 0.f;
+        auto rowadj = [&](int y) { return k0 * t_d[y][lb + 1] + cm * t_d[y][lb] + cp * t_d[y][lb + 2]; };
+        G[p] = gscale * (k0 * rowadj(la + 1) + rm * rowadj(la) + rp * rowadj(la + 2));
         if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) {
             v[0] = (double)b;
             v[1] = (double)b * (double)b;
