@@ -1117,33 +1117,36 @@ k_stats_gimage_gm(const float *__restrict__ in0, int64_t in_stride, int H, int W
         const float r_centre = -4.f * (t5[2][0] + t5[2][4]) + 8.f * (t5[2][1] + t5[2][3]) + 24.f * t5[2][2];
         G[(int64_t)i * W + j] = gscale * 0.125f * (r_outer + r_mid + r_centre);
         v[0] = (double)(gxc * gxc + gyc * gyc);
-    } else if (i < H && j < W) {
-        // Sobel/8 responses of the 3x3 neighbourhood (the centre one also feeds the statistics)
-        float gx[3][3], gy[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const float(*t)[kGmTileW + 4 + 1] = tile;
-                const int y = la + a, x = lb + b;  // top-left of the 3x3 window of output pixel (i + a - 1, j + b - 1)
-                gx[a][b] = ((t[y + 2][x] + 2.f * t[y + 2][x + 1] + t[y + 2][x + 2]) - (t[y][x] + 2.f * t[y][x + 1] + t[y][x + 2])) * 0.125f;
-                gy[a][b] = ((t[y][x + 2] + 2.f * t[y + 1][x + 2] + t[y + 2][x + 2]) - (t[y][x] + 2.f * t[y + 1][x] + t[y + 2][x])) * 0.125f;
-            }
-        // transpose: output pixel q = (i - a, j - b) reads this pixel with tap (a, b); q must lie in Omega
+    } else {
+        // Tiles along the border (workgroup-uniform; round 6).  They were the kernel's span: every thread computed the 18 Sobel responses of its
+        // 3 x 3 neighbourhood (108 LDS reads) and added them under per-tap tests of Omega.  Now in two steps on LDS tiles: the responses of the
+        // tile's pixels and a ring of one around them, ZERO outside Omega, once per pixel (12 reads); then the transpose as a plain 3 x 3
+        // correlation (18 reads, no tests) -- the same products in the same order, the skipped ones now zeros.
+        __shared__ float t_gx[kGmTileH + 2][kGmTileW + 2 + 1], t_gy[kGmTileH + 2][kGmTileW + 2 + 1];
+        for (int q = threadIdx.x; q < (kGmTileH + 2) * (kGmTileW + 2); q += 256) {
+            const int y = q / (kGmTileW + 2), x = q - y * (kGmTileW + 2);  // response of pixel (r0 + 1 + y, c0 + 1 + x): 3 x 3 window with top-left tile[y][x]
+            const float(*t)[kGmTileW + 4 + 1] = tile;
+            const int qi = r0 + 1 + y, qj = c0 + 1 + x;
+            const bool in_om = qi >= i0 && qi < H - i0 && qj >= i0 && qj < W - i0;
+            const float rx = ((t[y + 2][x] + 2.f * t[y + 2][x + 1] + t[y + 2][x + 2]) - (t[y][x] + 2.f * t[y][x + 1] + t[y][x + 2])) * 0.125f;
+            const float ry = ((t[y][x + 2] + 2.f * t[y + 1][x + 2] + t[y + 2][x + 2]) - (t[y][x] + 2.f * t[y + 1][x] + t[y + 2][x])) * 0.125f;
+            t_gx[y][x] = in_om ? rx : 0.f;
+            t_gy[y][x] = in_om ? ry : 0.f;
+        }
+        __syncthreads();
+        // transpose: output pixel q = (i - a, j - b) reads this pixel with tap (a, b); q outside Omega holds zeros
         float s = 0.f;
 #pragma unroll
         for (int a = -1; a <= 1; ++a)
 #pragma unroll
             for (int b = -1; b <= 1; ++b) {
-                const int qi = i - a, qj = j - b;
-                if (qi < i0 || qi >= H - i0 || qj < i0 || qj >= W - i0) continue;
                 const float sx = (float)a * (b == 0 ? 2.f : 1.f);  // SX[a+1][b+1] = a * (2 - |b|)
                 const float sy = (float)b * (a == 0 ? 2.f : 1.f);  // SY[a+1][b+1] = b * (2 - |a|)
-                s += gx[1 - a][1 - b] * sx + gy[1 - a][1 - b] * sy;
+                s += t_gx[la + 1 - a][lb + 1 - b] * sx + t_gy[la + 1 - a][lb + 1 - b] * sy;
             }
-        const int64_t p = (int64_t)i * W + j;
-        G[p] = gscale * s;
-        if (i >= i0 && i < H - i0 && j >= i0 && j < W - i0) v[0] = (double)(gx[1][1] * gx[1][1] + gy[1][1] * gy[1][1]);
+        if (i < H && j < W) G[(int64_t)i * W + j] = gscale * s;
+        const float gxc = t_gx[la + 1][lb + 1], gyc = t_gy[la + 1][lb + 1];  // (zero outside Omega, the image included)
+        v[0] = (double)(gxc * gxc + gyc * gyc);
     }
     CMAX_STAMP(2, 5);
     block_sum<2>(v, smem);
