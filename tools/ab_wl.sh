@@ -5,6 +5,6 @@ mkdir -p gpurun_out
 for lib in "$@"; do
   tag=$(basename $lib .so)
   if [ "$lib" = "default" ]; then unset CMAX_LIB; else export CMAX_LIB=$lib; fi
-  timeout 600 python bench.py --verbose --no-cpu-baseline --no-also --workload $wl --steps 100 --windows 11 > gpurun_out/abwl_$tag.log 2>&1 || tail -5 gpurun_out/abwl_$tag.log
+  timeout 600 python bench.py --verbose --no-cpu-baseline --no-also --no-pmc --workload $wl --steps 100 --windows 11 > gpurun_out/abwl_$tag.log 2>&1 || tail -5 gpurun_out/abwl_$tag.log
   python tools/bench_compact.py gpurun_out/abwl_$tag.log "[$tag]"
 done

@@ -63,7 +63,7 @@ for wl in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm"):
     print(wl, traffic)
 
 # SQ counters of the event kernels (tools/prof_sq.sh: three passes of 8 SQ counters, no tracing)
-for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
+for wl in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5_strong", "hbm"):
     f = os.path.join(src, "refresh", "sq_%s.json" % wl)
     if os.path.exists(f):
         doc = {"_comment": "rocprofv3 --pmc <8 SQ counters> x 3 passes -- python bench.py --no-cpu-baseline --no-also --steps 20 --warmup 3 "

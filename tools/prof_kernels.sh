@@ -5,7 +5,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-timeout 240 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python bench.py --verbose --no-cpu-baseline --no-also --windows 3 --ramp 0 "$@" > $out/bench.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python bench.py --verbose --no-cpu-baseline --no-also --no-pmc --windows 3 --ramp 0 "$@" > $out/bench.log 2>&1
 echo "[$tag] rocprofv3 rc=$?"
 python - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections

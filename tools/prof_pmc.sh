@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_${tag}_$ctr
   mkdir -p $out
-  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $out -o c -- python bench.py --no-cpu-baseline --no-also --windows 2 --steps 20 --warmup 3 --ramp 0 "$@" > $out/bench.log 2>&1
+  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $out -o c -- python bench.py --no-cpu-baseline --no-also --no-pmc --windows 2 --steps 20 --warmup 3 --ramp 0 "$@" > $out/bench.log 2>&1
   echo "[$tag $ctr] rc=$?"
 done
 python - "$tag" <<'PY'

@@ -12,7 +12,7 @@ for set in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   out=gpurun_out/sq_${tag}_p$i
   mkdir -p $out
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $out -o c -- python bench.py --no-cpu-baseline --no-also --steps 20 --warmup 3 --windows 2 --ramp 0 "$@" > $out/bench.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $out -o c -- python bench.py --no-cpu-baseline --no-also --no-pmc --steps 20 --warmup 3 --windows 2 --ramp 0 "$@" > $out/bench.log 2>&1
   echo "[$tag pass $i] rc=$?"
 done
 python - "$tag" <<'PY'
