@@ -634,8 +634,43 @@ def comm_probe_run(dev, world, rank, args, reps=50):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         nbytes = count * (8 if dtype == torch.float64 else 4)
         rows[name] = {"bytes": nbytes, "us": _r(float(t.item())), "model_us": _r(comm_model_us(nbytes, world))}
+    # ... and what the ROW-BAND partition would exchange instead of C1: cfg5's 20 halo rows (102 KB) to the next rank and
+    # from the previous one, as one grouped send / receive pair -- measures alpha_p2p, the one number that model assumes and no all-reduce shows
+    halo = None
+    try:
+        count = BAND_MODEL["halo_rows"] * 1280
+        send, recv = torch.zeros(count, dtype=torch.float32, device=dev), torch.empty(count, dtype=torch.float32, device=dev)
+        nxt, prv = (rank + 1) % world, (rank - 1) % world
+
+        def exchange():
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt), dist.P2POp(dist.irecv, recv, prv)]):
+                r.wait()
+
+        for _ in range(5):
+            exchange()
+        wins = []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                exchange()
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t0) / reps * 1e6)
+        t = torch.tensor([float(np.median(wins))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        halo = {"bytes": count * 4, "us": _r(float(t.item())),
+                "model_us": _r(BAND_MODEL["alpha_p2p_us"] + count * 4 / (COMM_MODEL["beta_GBps"] * 1e3)),
+                "note": "torch.distributed batch_isend_irecv ring (next / previous rank), host-waited per exchange: an upper bound of a stream-ordered ncclSend / ncclRecv pair"}
+    except Exception as e:  # noqa: BLE001 (a side figure; every rank takes the same path up to here)
+        halo = {"error": f"{type(e).__name__}: {e}"[:200]}
+    f1 = lambda m: 19.3 + 3.29 * m  # one-GPU us per evaluation at 720p from the measured 2.5M ... 64M-event rows
+    band = {"cfg5_20M_fused": _r(band_model_us(f1(20.0 / world), 1280, world, patch_gradient=False)),
+            "cfg5_20M_solver_objective": _r(band_model_us(f1(20.0 / world), 1280, world)),
+            "hbm_64M_fused": _r(band_model_us(f1(64.0 / world), 1280, world, patch_gradient=False))}
     handle.close()
     return {"collectives": sliced.collectives, "n_ranks": world, "model": COMM_MODEL, "allreduce": rows,
+            "band_partition": {"assumed": BAND_MODEL, "halo_exchange": halo, "model_us_per_evaluation": band},
             "note": "us = measured per call (back-to-back calls on one stream, max over ranks); model_us = DESIGN.md section 5's alpha-beta prediction"}
 
 
