@@ -362,8 +362,11 @@ int cmax_comm_allreduce(cmax_handle_t h, void *buf, int64_t count, int dtype, in
  * finish their gradient first and issue the same exchanges behind it.  bands = 1 (default): one all-reduce.  Same results. */
 int cmax_comm_set_c2_bands(cmax_handle_t h, int bands);
 /* One evaluation of the whole (time-sliced) batch: same arguments and results as cmax_objective,
- * the same on every rank (the gradient bit for bit; the loss up to fp64 summation order when a rank
- * holds no events).  A rank may hold zero events.  Without a communicator: == cmax_objective.   */
+ * the same on every rank BIT FOR BIT -- the gradient because it is all-reduced, result[8] because
+ * it leaves as rank 0's (every other rank zeroes its eight doubles and they ride in the gradient's
+ * all-reduce as one grouped call; a value-only evaluation exchanges the 64 bytes alone): replicated
+ * optimisers (src/solver/scipy_autograd/scipy_minimize.py:100-117 on every rank) take identical
+ * decisions.  A rank may hold zero events.  Without a communicator: == cmax_objective.          */
 int cmax_objective_dist(cmax_handle_t h, const cmax_objective_t *desc_host, const void *motion,
                         double *result, void *grad, cmax_stream_t stream);
 
