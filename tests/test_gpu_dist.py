@@ -102,7 +102,12 @@ def test_objective_dist_world1_rccl(world1_nccl, model, cost, sigma, Tn):
     call, res_p, grad_p = h.prepare(desc, motion, dist=True)
     call()
     torch.cuda.synchronize()
-    assert abs(res_p[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item()) and rel_max(grad_p.cpu().numpy(), grad.cpu().numpy()) <= 2e-6
+    assert abs(res_p[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item()) and rel_max(grad_p.cpu().numpy(), grad.cpu().numpy()) <= 5e-6
+    # value only: no gradient to carry result[8] -- the 64 bytes are exchanged on their own (rank-consistent scalars, round 6)
+    for _ in range(2):
+        res_v, grad_v = h.evaluate_dist(desc, motion, want_grad=False)
+    torch.cuda.synchronize()
+    assert grad_v is None and abs(res_v[0].item() - res[0].item()) <= 1e-6 * abs(res[0].item())
     # the raw collective entry: a 1-rank all-reduce leaves the buffer as it is
     t = torch.arange(8, dtype=torch.float64, device="cuda")
     h.comm_allreduce(t, "min")
