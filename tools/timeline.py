@@ -58,6 +58,8 @@ def run(name):
         last = np.max(np.where(a > 0, a, 0), axis=1)
         print(f" {('K1', 'K3', 'image kernel')[k]}: {len(a)} workgroups stamped; first starts at {(start - t00) / 100:.2f} us, starts spread over {(a[:, 0].max() - start) / 100:.2f} us, "
               f"last stamp at {(last.max() - t00) / 100:.2f} us (span {(last.max() - start) / 100:.2f} us)")
+        st = np.sort((a[:, 0] - start) / 100.0)
+        print(f"    starts: {int((st <= 1.0).sum())} within 1 us, {int((st <= 2.0).sum())} within 2 us, {int((st > 4.0).sum())} later than 4 us (latest {st[-1]:.2f} us)")
         prev = 0
         for i in range(1, 8):
             ok = a[:, i] > 0
